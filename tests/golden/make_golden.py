@@ -1,0 +1,272 @@
+#!/opt/conda/bin/python3.9
+"""Generate the committed golden vectors from the REAL reference.
+
+Runs ONLY in the build container (needs /root/reference, scikit-image and
+PyWavelets: /opt/conda/bin/python3.9) after `sh oracle/build_ref.sh`:
+
+    PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+It imports the reference's own internetarchivepdf/mrc.py and Cython kernels via
+oracle/ref_loader.py, feeds them deterministic inputs (mrchip.synth, seeded
+numpy RandomState streams stored in the fixture where used) and stores inputs'
+digests + expected outputs.  Fixtures are data only: no reference source text.
+
+Files written next to this script:
+  kernels.npz     sauvola / threshold_image / fast_mask_denoise / optimise_* cases
+  thirdparty.npz  convert('L'), estimate_sigma, estimate_noise, gaussian_filter, thumbnail
+  pages.npz       full create_mrc_hocr_components on small synthetic pages
+  digests.json    SHA-256 of outputs at BASELINE.json config sizes
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+import warnings
+
+warnings.simplefilter('ignore')
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+
+import numpy as np  # noqa: E402
+from PIL import Image  # noqa: E402
+import ref_loader  # noqa: E402
+from mrchip import synth  # noqa: E402
+
+mrc = ref_loader.load_mrc()
+ref_sauvola, ref_optimiser = ref_loader.load_cython()
+from skimage.restoration import estimate_sigma  # noqa: E402
+from scipy import ndimage  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def kernels():
+    rng = np.random.RandomState(20260213)
+    d = {}
+    meta = []
+    # --- binarise_sauvola -------------------------------------------------
+    cases = [(96, 128, 31, 31, 0.34, 'kat'), (96, 128, 101, 101, 0.1, 'kat'), (96, 128, 30, 30, -0.2, 'kat'),
+             (120, 160, 51, 51, 0.34, 'rand'), (120, 160, 51, 51, 0.1, 'flat'), (7, 5, 51, 51, 0.1, 'rand'),
+             (1, 1, 51, 51, 0.34, 'rand'), (150, 40, 25, 51, 0.34, 'rand'), (64, 300, 15, 7, 0.5, 'rand'),
+             (90, 130, 91, 91, 0.34, 'text'), (33, 500, 51, 51, 0.1, 'text'), (200, 200, 2, 2, 0.34, 'rand'),
+             (64, 64, 1, 1, 0.34, 'rand'), (128, 96, 51, 51, 0.0, 'rand')]
+    for i, (h, w, ww, wh, k, kind) in enumerate(cases):
+        if kind == 'kat':
+            img = synth.kat_pattern(w, h)
+        elif kind == 'rand':
+            img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        elif kind == 'flat':
+            img = np.clip(rng.normal(128, 2, (h, w)), 0, 255).astype(np.uint8)
+        else:
+            img = synth.synth_page(w, h, 1, seed=i, noise_sigma=4.0, line_div=6)[0]
+        out = np.empty(h * w, dtype=np.uint8)
+        ref_sauvola.binarise_sauvola(img.reshape(-1), out, w, h, ww, wh, k, 128.0)
+        d['sau_in_%d' % i] = img
+        d['sau_out_%d' % i] = np.packbits(out.reshape(h, w), axis=1)
+        meta.append(('sauvola', i, h, w, ww, wh, k))
+    # --- threshold_image (KAT2 of SURVEY 8c) ---------------------------------
+    pat = synth.kat_pattern(1200, 1600)      # SURVEY writes pat(H, W)
+    t = mrc.threshold_image(pat, 124)
+    d['thr_kat2_bits'] = np.packbits(t, axis=1)
+    assert sha(t)[:16] == '7e6d215db2679515' and int(t.sum()) == 203520, (sha(t)[:16], t.sum())
+    for j, (dpi, k) in enumerate([(None, 0.34), (100, 0.1), (400, 0.34), (8, 0.34)]):
+        img = synth.synth_page(300, 200, 1, seed=40 + j, noise_sigma=5.0, line_div=10)[0]
+        d['thr_out_%d' % j] = np.packbits(mrc.threshold_image(img, dpi, k), axis=1)
+        meta.append(('threshold', j, 200, 300, -1 if dpi is None else dpi, 0, k))
+    # --- fast_mask_denoise -------------------------------------------------------
+    dn = [(100, 120, 0.1, 4, 2), (64, 64, 0.5, 4, 2), (150, 200, 0.03, 4, 2), (5, 5, 0.9, 4, 2), (4, 9, 0.9, 4, 2),
+          (80, 80, 0.3, 2, 1), (80, 90, 0.4, 6, 3), (60, 400, -1, 4, 2), (400, 60, -2, 4, 2)]
+    for i, (h, w, dens, mincnt, n) in enumerate(dn):
+        if dens == -1:      # thin horizontal rules: the removal cascades along the row
+            m = np.zeros((h, w), dtype=bool)
+            m[10, 5:w - 5] = True
+            m[20:22, 5:w - 5] = True
+            m[30, 5:w // 2] = True
+            m[31, w // 2 - 3:w - 5] = True
+        elif dens == -2:    # thin vertical rules: the removal cascades down the column
+            m = np.zeros((h, w), dtype=bool)
+            m[5:h - 5, 10] = True
+            m[5:h - 5, 20:22] = True
+            m[5:h // 2, 30] = True
+            m[h // 2 - 3:h - 5, 31] = True
+        else:
+            m = rng.rand(h, w) < dens
+        out = m.copy()
+        ref_optimiser.fast_mask_denoise(out.view(np.uint8), w, h, mincnt, n)
+        d['dn_in_%d' % i] = np.packbits(m, axis=1)
+        d['dn_out_%d' % i] = np.packbits(out, axis=1)
+        meta.append(('denoise', i, h, w, mincnt, n, 0))
+    # KAT3 (salted masks) digests are in digests.json
+    # --- optimise ----------------------------------------------------------------
+    oc = [(60, 80, 0.1, 3), (60, 80, 0.1, 10), (33, 47, 0.5, 10), (100, 100, 0.01, 3), (50, 50, 0.0, 3),
+          (5, 4, 0.3, 10), (64, 256, 0.9, 3), (256, 64, 0.2, 10), (40, 40, 1.0, 3)]
+    for i, (h, w, dens, n) in enumerate(oc):
+        m = (rng.rand(h, w) < dens)
+        g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        c = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        d['opt_mask_%d' % i] = np.packbits(m, axis=1)
+        d['opt_g_%d' % i] = g
+        d['opt_c_%d' % i] = c
+        d['opt_g2_%d' % i] = ref_optimiser.optimise_gray2(m.view(np.uint8), g, w, h, n)
+        d['opt_c2_%d' % i] = ref_optimiser.optimise_rgb2(m.view(np.uint8), c, w, h, n)
+        assert np.array_equal(d['opt_g2_%d' % i], ref_optimiser.optimise_gray(m.view(np.uint8), g, w, h, n))
+        assert np.array_equal(d['opt_c2_%d' % i], ref_optimiser.optimise_rgb(m.view(np.uint8), c, w, h, n))
+        meta.append(('optimise', i, h, w, n, 0, 0))
+    d['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'kernels.npz'), **d)
+
+
+def thirdparty():
+    rng = np.random.RandomState(77)
+    d = {}
+    meta = []
+    c = rng.randint(0, 256, (50, 60, 3)).astype(np.uint8)
+    d['luma_in'] = c
+    d['luma_out'] = np.array(Image.fromarray(c).convert('L'))
+    for i, (h, w) in enumerate([(100, 120), (101, 121), (37, 64), (64, 37), (9, 9), (150, 201)]):
+        f = rng.randint(0, 256, (h, w)).astype(np.float32)
+        b = rng.rand(h, w) < 0.2
+        d['sig_f_%d' % i] = f.astype(np.uint8)
+        d['sig_b_%d' % i] = np.packbits(b, axis=1)
+        import pywt
+        d['sig_dd_%d' % i] = pywt.dwtn(f, 'db2')['dd']
+        d['sig_vals_%d' % i] = np.array([float(np.mean(estimate_sigma(f))), float(np.mean(estimate_sigma(b))),
+                                         float(mrc.estimate_noise(f))])
+        meta.append(('sigma', i, h, w))
+    for i, sig in enumerate([0.13, 0.2, 0.37, 0.5, 0.61, 0.9, 1.2, 1.5, 2.3]):
+        h, w = [(50, 61), (64, 64), (3, 200), (7, 5), (61, 50)][i % 5]
+        f = rng.randint(0, 256, (h, w)).astype(np.float32)
+        d['gau_in_%d' % i] = f.astype(np.uint8)
+        d['gau_out_%d' % i] = ndimage.filters.gaussian_filter(f, sigma=sig)
+        radius = int(4.0 * sig + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sig * sig) * x ** 2)
+        d['gau_w_%d' % i] = (phi / phi.sum())[::-1]
+        meta.append(('gauss', i, h, w, sig))
+    i = 0
+    for (h, w) in [(120, 160), (121, 163), (67, 200), (200, 67), (64, 48), (37, 41)]:
+        for f in [2, 3, 4, 5, 6, 8]:
+            for ch in (1, 3):
+                im = rng.randint(0, 256, (h, w) if ch == 1 else (h, w, 3)).astype(np.uint8)
+                wd, hd = int(w / f), int(h / f)
+                if wd <= 0 or hd <= 0:
+                    continue
+                pi = Image.fromarray(im)
+                pi.thumbnail((wd, hd))
+                d['thb_in_%d' % i] = im
+                d['thb_out_%d' % i] = np.array(pi)
+                meta.append(('thumb', i, h, w, f, ch))
+                i += 1
+    d['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'thirdparty.npz'), **d)
+
+
+PAGE_CASES = [
+    # w, h, channels, seed, noise_sigma, dpi, downsample, bg_downsample, fg_downsample, denoise
+    (400, 320, 3, 0, 6.0, None, None, 3, None, 'fast'),
+    (400, 320, 1, 1, 6.0, None, None, 3, None, 'fast'),
+    (320, 240, 3, 2, 0.0, None, None, 3, 2, 'fast'),
+    (401, 303, 3, 3, 2.0, 150, None, 4, None, 'fast'),
+    (450, 350, 3, 4, 12.0, 200, None, None, 4, 'fast'),
+    (400, 320, 3, 5, 6.0, None, None, None, None, 'none'),
+    (400, 320, 3, 6, 25.0, 100, None, 5, 3, 'fast'),
+    (300, 200, 1, 7, 3.0, None, 2, 1000, None, 'fast'),   # hOCR coords /2; bg too small to downsample
+]
+
+
+def run_ref_page(w, h, ch, seed, ns, dpi, ds, bgd, fgd, dn, line_div=16):
+    img, hocr = synth.synth_page(w * (ds or 1), h * (ds or 1), ch, seed=seed, noise_sigma=ns, line_div=line_div)
+    if ds:
+        # the caller downsamples the page, the hOCR stays in original coordinates (recode.py:368-374)
+        img = np.ascontiguousarray(img[::ds, ::ds])
+    td, er = [], set()
+    g = mrc.create_mrc_hocr_components(Image.fromarray(img), hocr, dpi=dpi, downsample=ds, bg_downsample=bgd,
+                                       fg_downsample=fgd, denoise_mask=dn, timing_data=td, errors=er)
+    m = next(g).copy()
+    fg = next(g)
+    bg = next(g)
+    try:
+        next(g)
+        raise AssertionError('generator should be exhausted')
+    except StopIteration:
+        pass
+    return img, hocr, m, fg, bg, [k for k, _ in td], sorted(er)
+
+
+def pages():
+    d = {}
+    meta = []
+    for i, case in enumerate(PAGE_CASES):
+        img, hocr, m, fg, bg, keys, errs = run_ref_page(*case)
+        d['pg_img_sha_%d' % i] = np.array(sha(img))
+        d['pg_mask_%d' % i] = np.packbits(m, axis=1)
+        d['pg_fg_%d' % i] = fg
+        d['pg_bg_%d' % i] = bg
+        meta.append({'case': case, 'keys': keys, 'errors': errs, 'mask_sum': int(m.sum())})
+    d['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'pages.npz'), **d)
+
+
+def digests():
+    out = {}
+    # config 1: 1200x1600 gray, dpi=124 (window 31), threshold_image only
+    img = synth.synth_page(1200, 1600, 1, seed=101, noise_sigma=6.0)[0]
+    t = mrc.threshold_image(img, 124)
+    out['c1_threshold'] = {'in': sha(img), 'out': sha(t), 'sum': int(t.sum())}
+    # config 2: 4000x3000 RGB + hOCR, bg/3, dpi None and dpi 400
+    for tag, dpi in (('c2_dpiNone', None), ('c2_dpi400', 400)):
+        t0 = time.time()
+        img, hocr, m, fg, bg, keys, errs = run_ref_page(4000, 3000, 3, 202, 6.0, dpi, None, 3, None, 'fast', 60)
+        out[tag] = {'in': sha(img), 'mask': sha(m), 'mask_sum': int(m.sum()), 'fg': sha(fg), 'bg': sha(bg),
+                    'bg_shape': list(bg.shape), 'keys': keys, 'ref_seconds': round(time.time() - t0, 2)}
+    # config 3 shape: 3300x4600 gray sauvola window 51
+    img = synth.synth_page(3300, 4600, 1, seed=303, noise_sigma=6.0)[0]
+    t = mrc.threshold_image(img, None)
+    out['c3_threshold'] = {'in': sha(img), 'out': sha(t), 'sum': int(t.sum())}
+    # config 5 shape (quarter-size to keep generation time sane): 8000x6000 dpi=364 fg/bg /4
+    t0 = time.time()
+    img, hocr, m, fg, bg, keys, errs = run_ref_page(8000, 6000, 3, 505, 6.0, 364, None, 4, 4, 'fast', 60)
+    out['c5'] = {'in': sha(img), 'mask': sha(m), 'mask_sum': int(m.sum()), 'fg': sha(fg), 'bg': sha(bg),
+                 'fg_shape': list(fg.shape), 'bg_shape': list(bg.shape), 'keys': keys,
+                 'ref_seconds': round(time.time() - t0, 2)}
+    # KAT3..KAT6 of SURVEY 8c (digest-only known answers)
+    pat = synth.kat_pattern(1200, 1600)
+    m0 = mrc.threshold_image(pat, 124)
+    yy, xx = np.mgrid[0:1600, 0:1200].astype(np.int64)
+    kat3 = {}
+    for M in (97, 13, 5):
+        m = m0 | (((7919 * xx + 104729 * yy + 31 * xx * yy) % M) == 0)
+        r = m.copy()
+        ref_optimiser.fast_mask_denoise(r.view(np.uint8), 1200, 1600, 4, 2)
+        kat3[str(M)] = {'in': sha(m), 'in_sum': int(m.sum()), 'out': sha(r), 'out_sum': int(r.sum())}
+    out['kat3'] = kat3
+    pat3 = synth.kat_pattern(1200, 1600, 3)
+    out['kat4a'] = sha(ref_optimiser.optimise_rgb2(m0.view(np.uint8), pat3, 1200, 1600, 3))
+    out['kat4b'] = sha(ref_optimiser.optimise_rgb2((~m0).view(np.uint8), pat3, 1200, 1600, 10))
+    out['kat4c'] = sha(ref_optimiser.optimise_gray2(m0.view(np.uint8), pat, 1200, 1600, 3))
+    p = synth.kat_pattern(800, 600, 3)
+    assert kat3['97']['out'][:16] == 'f6219d8bc085c372' and kat3['13']['out'][:16] == 'b05a62586fade3cf'
+    assert kat3['5']['out'][:16] == '245ce24f531b7e29'
+    assert out['kat4a'][:16] == '85c1b25747f9b565' and out['kat4b'][:16] == '0a1ed795578605cf'
+    assert out['kat4c'][:16] == '8a9fc9e1d7614c1c'
+    out['kat6'] = float(mrc.estimate_noise(np.array(Image.fromarray(p).convert('L'), dtype=np.float32)))
+    assert out['kat6'] == 15.725569182346643, out['kat6']
+    out['versions'] = {'numpy': np.__version__, 'pillow': Image.__version__ if hasattr(Image, '__version__') else '',
+                       'python': sys.version.split()[0]}
+    import scipy, skimage, pywt
+    out['versions'].update(scipy=scipy.__version__, skimage=skimage.__version__, pywt=pywt.__version__)
+    with open(os.path.join(HERE, 'digests.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests']
+    for name in which:
+        t0 = time.time()
+        globals()[name]()
+        print(name, 'done in %.1fs' % (time.time() - t0))
