@@ -1,0 +1,227 @@
+// Context, caching device allocator, staging copies and HIP-event profiling.
+#include <cstdarg>
+
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    int best = -1;
+    for (size_t i = 0; i < ctx->blocks.size(); i++) {
+        DevBlock &b = ctx->blocks[i];
+        if (!b.busy && b.bytes >= bytes && b.bytes <= bytes * 2 + (1 << 20))
+            if (best < 0 || b.bytes < ctx->blocks[best].bytes) best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->blocks[best].busy = true;
+        *out = ctx->blocks[best].base;
+        return 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto &b : ctx->blocks)
+            if (!b.busy && b.base) { (void)hipFree(b.base); b.base = nullptr; b.bytes = 0; }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return MRCHIP_E_NOMEM;
+        }
+    }
+    DevBlock b;
+    b.base = p; b.bytes = bytes; b.busy = true;
+    ctx->blocks.push_back(b);
+    *out = p;
+    return 0;
+}
+
+void dev_free(mrchip_ctx *ctx, void *p) {
+    for (auto &b : ctx->blocks)
+        if (b.base == p) { b.busy = false; return; }
+}
+
+int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+static hipEvent_t get_event(mrchip_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int prof_begin(mrchip_ctx *ctx, hipStream_t s, const char *name, double alg_bytes) {
+    if (!ctx->prof) return -1;
+    int idx = -1;
+    for (size_t i = 0; i < ctx->prof_entries.size(); i++)
+        if (ctx->prof_entries[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) {
+        ProfEntry e;
+        e.name = name;
+        ctx->prof_entries.push_back(e);
+        idx = (int)ctx->prof_entries.size() - 1;
+    }
+    ctx->prof_entries[idx].launches++;
+    ctx->prof_entries[idx].alg_bytes += alg_bytes;
+    ProfPending p;
+    p.entry = idx;
+    p.a = get_event(ctx);
+    p.b = get_event(ctx);
+    (void)hipEventRecord(p.a, s);
+    ctx->prof_pending.push_back(p);
+    return (int)ctx->prof_pending.size() - 1;
+}
+
+void prof_end(mrchip_ctx *ctx, hipStream_t s, int token) {
+    if (token < 0) return;
+    (void)hipEventRecord(ctx->prof_pending[token].b, s);
+}
+
+int prof_resolve(mrchip_ctx *ctx) {
+    for (auto &p : ctx->prof_pending) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        ctx->prof_entries[p.entry].ms += ms;
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
+    return 0;
+}
+
+}  // namespace mrchip
+
+using namespace mrchip;
+
+MRCHIP_EXPORT int mrchip_abi_version(void) { return MRCHIP_ABI_VERSION; }
+
+MRCHIP_EXPORT const char *mrchip_last_error(void) { return g_err; }
+
+MRCHIP_EXPORT int mrchip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+MRCHIP_EXPORT mrchip_ctx *mrchip_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libmrchip has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d devices)", device, n);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return nullptr;
+    }
+    mrchip_ctx *ctx = new mrchip_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->cus = prop.multiProcessorCount;
+        ctx->hbm = prop.totalGlobalMem;
+        snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    for (int i = 0; i < NSTREAMS; i++) {
+        if ((e = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking)) != hipSuccess) {
+            set_error("hipStreamCreate: %s", hipGetErrorString(e));
+            delete ctx;
+            return nullptr;
+        }
+    }
+    ctx->pinned_bytes = 1 << 20;
+    if ((e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault)) != hipSuccess) {
+        set_error("hipHostMalloc: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+MRCHIP_EXPORT void mrchip_destroy(mrchip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &b : ctx->blocks)
+        if (b.base) (void)hipFree(b.base);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < NSTREAMS; i++)
+        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
+    delete ctx;
+}
+
+MRCHIP_EXPORT int mrchip_sync(mrchip_ctx *ctx) {
+    if (!ctx) return MRCHIP_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int i = 0; i < NSTREAMS; i++) HIP_TRY(hipStreamSynchronize(ctx->streams[i]));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes) {
+    if (!ctx) return MRCHIP_E_ARG;
+    if (name && name_len > 0) snprintf(name, name_len, "%s", ctx->name);
+    if (cus) *cus = ctx->cus;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm;
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_prof_enable(mrchip_ctx *ctx, int enable) {
+    if (!ctx) return MRCHIP_E_ARG;
+    if (!enable) TRY(prof_resolve(ctx));
+    ctx->prof = enable != 0;
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_prof_reset(mrchip_ctx *ctx) {
+    if (!ctx) return MRCHIP_E_ARG;
+    TRY(prof_resolve(ctx));
+    ctx->prof_entries.clear();
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_prof_count(mrchip_ctx *ctx) {
+    if (!ctx) return MRCHIP_E_ARG;
+    TRY(prof_resolve(ctx));
+    return (int)ctx->prof_entries.size();
+}
+
+MRCHIP_EXPORT int mrchip_prof_get(mrchip_ctx *ctx, int i, char *name, int name_len, long long *launches,
+                                  double *total_ms, double *alg_bytes) {
+    if (!ctx || i < 0 || i >= (int)ctx->prof_entries.size()) return MRCHIP_E_ARG;
+    const ProfEntry &e = ctx->prof_entries[i];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", e.name.c_str());
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    if (alg_bytes) *alg_bytes = e.alg_bytes;
+    return 0;
+}

@@ -1,0 +1,314 @@
+// Sauvola adaptive threshold (reference: cython/sauvola.pyx:29-222, closed form in
+// SURVEY.md 8a row a1) for gfx950.
+//
+// Decomposition: one 64-lane wave per tile (workgroup = 1 wave, so the
+// write->read hand-off through LDS needs no cross-wave barrier).  A tile is a
+// strip of CW = 64*K input columns (K adjacent columns per lane, loaded as one
+// aligned K-byte vector) by `rows` output rows.  Each lane keeps the vertical
+// window sums of its K columns (sum and sum of squares, int32 like the
+// reference's `integral` arrays, pyx:64-65) in registers and slides them down
+// the strip: +entering row, -leaving row.  Per output row the wave builds the
+// exclusive prefix of the column sums across the strip (K-element serial prefix
+// per lane + one DPP wave scan of the lane totals), parks it in LDS, and every
+// output pixel takes its horizontal window as a difference of two prefix
+// values.  Everything is integer (mod 2^32, exact because a window sum of
+// squares stays below 2^32 for windows up to 257x257) until the final
+// comparison, which is evaluated in fp64 in the reference's operation order
+// with contraction off.
+//
+// HBM traffic per pixel: 1 B read (+ halo re-reads served by L2: each input row
+// is touched three times by the same wave -- entering, centre, leaving) + 1 B
+// written.  Algorithmic bytes: 2*w*h.
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+struct SauvolaParams {
+    int ww, wh;       // window
+    int l, r, o, u;   // l=(ww+1)/2 r=ww/2 o=(wh+1)/2 u=wh/2  (pyx:76-79)
+    double k, km1, k2;
+    int flags;
+    int two;          // output columns per tile
+    int th;           // output rows per tile
+};
+
+// inclusive wave scan (64 lanes) with DPP row shifts + row broadcasts (GFX9)
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
+    unsigned x = v;
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return x;
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int K>
+struct Vec;
+template <>
+struct Vec<4> { using T = unsigned int; };
+template <>
+struct Vec<8> { using T = uint2; };
+template <>
+struct Vec<16> { using T = uint4; };
+
+template <int K>
+__device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) {
+    using V = typename Vec<K>::T;
+    V v = *reinterpret_cast<const V *>(p);
+    if constexpr (K == 4) { w[0] = v; }
+    if constexpr (K == 8) { w[0] = v.x; w[1] = v.y; }
+    if constexpr (K == 16) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+}
+
+// the reference's decision (pyx:143-153) for one pixel; returns `form`
+__device__ __forceinline__ bool sauvola_form(unsigned S, unsigned Q, unsigned count, unsigned px,
+                                             double k, double km1, double k2) {
+    double mean = (double)(S / count);              // C integer division (cdivision)
+    double qd = (double)(Q / count);
+    double mm = __dmul_rn(mean, mean);
+    double variance = __dsub_rn(qd, mm);
+    double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
+    double lhs = __dmul_rn(tmp, tmp);
+    double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
+    if (k >= 0) return (tmp <= 0) || (lhs <= rhs);
+    return (tmp <= 0) && (lhs >= rhs);
+}
+
+template <int K, bool MULTI>
+__global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
+                                                     SauvolaParams P) {
+    constexpr int CW = 64 * K;
+    __shared__ __attribute__((aligned(16))) unsigned Es[CW];
+    __shared__ __attribute__((aligned(16))) unsigned Eq[CW];
+
+    SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
+    const int w = job.w, h = job.h;
+    const int X0 = blockIdx.x * P.two;
+    const int Y0 = blockIdx.y * P.th;
+    if (X0 >= w || Y0 >= h) return;
+    const int lane = threadIdx.x;
+    const int nout = min(P.two, w - X0);
+    const int rows = min(P.th, h - Y0);
+    const int l = P.l, r = P.r, o = P.o, u = P.u;
+
+    // first input column, aligned down so that every lane's K-byte load is aligned
+    int Xa = X0 - l + 1;
+    {
+        uintptr_t a = reinterpret_cast<uintptr_t>(job.src) + (intptr_t)Xa;
+        Xa -= (int)(a & (uintptr_t)(K - 1));
+    }
+    const int c0 = Xa + K * lane;          // this lane's first column
+    // per-byte validity mask of the K columns (columns outside [0,w) contribute 0)
+    unsigned vmask[K / 4];
+#pragma unroll
+    for (int q = 0; q < K / 4; q++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int c = c0 + 4 * q + b;
+            if (c >= 0 && c < w) m |= 0xffu << (8 * b);
+        }
+        vmask[q] = m;
+    }
+    const uint8_t *src0 = job.src + c0;
+
+    unsigned cs[K], cq[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { cs[i] = 0; cq[i] = 0; }
+
+    auto add_row = [&](int yy, bool plus) {
+        unsigned wv[K / 4];
+        load_px<K>(src0 + (size_t)yy * job.src_pitch, wv);
+#pragma unroll
+        for (int q = 0; q < K / 4; q++) {
+            unsigned v = wv[q] & vmask[q];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                unsigned p = (v >> (8 * b)) & 0xffu;
+                if (plus) { cs[4 * q + b] += p; cq[4 * q + b] += p * p; }
+                else      { cs[4 * q + b] -= p; cq[4 * q + b] -= p * p; }
+            }
+        }
+    };
+
+    // warm-up: rows [Y0-o, Y0+u-1] clipped to the image
+    for (int yy = max(0, Y0 - o); yy < min(h, Y0 + u); yy++) add_row(yy, true);
+
+    const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
+    const bool do_or = (P.flags & SAUVOLA_OR) != 0;
+    unsigned ones_a = 0, ones_b = 0;
+
+    for (int y = Y0; y < Y0 + rows; y++) {
+        if (y + u < h) add_row(y + u, true);
+        if (y - o >= 0) add_row(y - o, false);
+        const int nrows = min(y + u, h - 1) - max(y - o, -1);
+
+        // exclusive prefix over the strip's columns
+        unsigned ps[K], pq[K];
+        unsigned ts = 0, tq = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) { ps[i] = ts; pq[i] = tq; ts += cs[i]; tq += cq[i]; }
+        unsigned bs = wave_scan_incl(ts) - ts;
+        unsigned bq = wave_scan_incl(tq) - tq;
+        __syncthreads();   // previous row's readers are done (single-wave workgroup)
+#pragma unroll
+        for (int i = 0; i < K; i += 4) {
+            uint4 a = make_uint4(bs + ps[i], bs + ps[i + 1], bs + ps[i + 2], bs + ps[i + 3]);
+            uint4 b = make_uint4(bq + pq[i], bq + pq[i + 1], bq + pq[i + 2], bq + pq[i + 3]);
+            *reinterpret_cast<uint4 *>(&Es[K * lane + i]) = a;
+            *reinterpret_cast<uint4 *>(&Eq[K * lane + i]) = b;
+        }
+        __syncthreads();
+
+        // centre pixels of this row
+        unsigned cv[K / 4];
+        load_px<K>(src0 + (size_t)y * job.src_pitch, cv);
+
+        unsigned outa[K / 4], outb[K / 4];
+#pragma unroll
+        for (int q = 0; q < K / 4; q++) { outa[q] = 0; outb[q] = 0; }
+        bool any = false, all = true;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const int c = c0 + i;
+            const bool valid = (c >= X0) && (c < X0 + nout);
+            any |= valid;
+            all &= valid;
+            if (valid) {
+                const int ci = K * lane + i;
+                const unsigned S = Es[ci + r + 1] - Es[ci - l + 1];
+                const unsigned Q = Eq[ci + r + 1] - Eq[ci - l + 1];
+                const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
+                const unsigned count = (unsigned)(ncols * nrows);
+                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
+                bool form = sauvola_form(S, Q, count, px, P.k, P.km1, P.k2);
+                unsigned bit = (form ? 0u : 1u) ^ (invert ? 1u : 0u);   // pyx:153 (+ mrc.py:85)
+                outa[i / 4] |= bit << (8 * (i & 3));
+                ones_a += bit;
+                if (job.dst_inv) {
+                    // the same window on the image 255-p (mrc.py:224, 235)
+                    const unsigned Si = 255u * count - S;
+                    const unsigned Qi = 65025u * count - 510u * S + Q;
+                    bool fi = sauvola_form(Si, Qi, count, 255u - px, P.k, P.km1, P.k2);
+                    unsigned bi = (fi ? 0u : 1u) ^ (invert ? 1u : 0u);
+                    outb[i / 4] |= bi << (8 * (i & 3));
+                    ones_b += bi;
+                }
+            }
+        }
+        if (any) {
+            uint8_t *d = job.dst + (size_t)y * job.dst_pitch + c0;
+            const bool aligned = (reinterpret_cast<uintptr_t>(d) & 3u) == 0;
+            if (all && aligned) {
+#pragma unroll
+                for (int q = 0; q < K / 4; q++) {
+                    unsigned *dp = reinterpret_cast<unsigned *>(d) + q;
+                    *dp = do_or ? (*dp | outa[q]) : outa[q];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const int c = c0 + i;
+                    if (c >= X0 && c < X0 + nout) {
+                        uint8_t v = (uint8_t)((outa[i / 4] >> (8 * (i & 3))) & 0xffu);
+                        d[i] = do_or ? (uint8_t)(d[i] | v) : v;
+                    }
+                }
+            }
+            if (job.dst_inv) {
+                uint8_t *e = job.dst_inv + (size_t)y * job.dst_pitch + c0;
+                if (all && aligned) {
+#pragma unroll
+                    for (int q = 0; q < K / 4; q++) reinterpret_cast<unsigned *>(e)[q] = outb[q];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) {
+                        const int c = c0 + i;
+                        if (c >= X0 && c < X0 + nout)
+                            e[i] = (uint8_t)((outb[i / 4] >> (8 * (i & 3))) & 0xffu);
+                    }
+                }
+            }
+        }
+    }
+    if (job.counts) {
+        unsigned a = wave_sum(ones_a);
+        unsigned b = wave_sum(ones_b);
+        if (lane == 0) {
+            if (a) atomicAdd(&job.counts[0], a);
+            if (b) atomicAdd(&job.counts[1], b);
+        }
+    }
+}
+
+template <int K>
+static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, const SauvolaJob *d_jobs,
+                    int njobs, SauvolaParams P, int maxw, int maxh, double alg_bytes) {
+    constexpr int CW = 64 * K;
+    P.two = (CW - P.ww - K) & ~3;
+    if (P.two < 4) {
+        set_error("sauvola: window width %d too large for the %d-column strip", P.ww, CW);
+        return MRCHIP_E_UNSUPPORTED;
+    }
+    // rows per tile: enough tiles to fill the chip, but amortise the (wh-1)-row warm-up
+    int strips = cdiv(maxw, P.two);
+    int th = 64;
+    while (th > 16 && (long long)strips * cdiv(maxh, th) * njobs < 2048) th >>= 1;
+    P.th = th;
+    dim3 grid(strips, cdiv(maxh, th), njobs);
+    if (njobs == 1 && !d_jobs) {
+        LAUNCH(ctx, s, "sauvola", alg_bytes,
+               hipLaunchKernelGGL((sauvola_kernel<K, false>), grid, dim3(64), 0, s, h_jobs[0], nullptr, P));
+    } else {
+        LAUNCH(ctx, s, "sauvola_boxes", alg_bytes,
+               hipLaunchKernelGGL((sauvola_kernel<K, true>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
+    }
+    return 0;
+}
+
+// jobs: host array.  For njobs > 1 (or d_jobs != nullptr) the same array must
+// already be resident at d_jobs.
+int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, const SauvolaJob *d_jobs,
+                       int njobs, int ww, int wh, double k, double R, int flags) {
+    if (njobs <= 0) return 0;
+    if (ww < 1 || wh < 1) { set_error("sauvola: window must be >= 1"); return MRCHIP_E_ARG; }
+    if ((long long)ww * wh > 66051) {
+        set_error("sauvola: window %dx%d exceeds the 32-bit sum-of-squares range (area <= 66051)", ww, wh);
+        return MRCHIP_E_UNSUPPORTED;
+    }
+    SauvolaParams P;
+    P.ww = ww; P.wh = wh;
+    P.l = (ww + 1) / 2; P.r = ww / 2; P.o = (wh + 1) / 2; P.u = wh / 2;
+    P.k = k; P.km1 = k - 1; P.k2 = k * k / R / R;     // pyx:62
+    P.flags = flags;
+    int maxw = 0, maxh = 0;
+    double alg = 0;
+    for (int i = 0; i < njobs; i++) {
+        if (jobs[i].w > maxw) maxw = jobs[i].w;
+        if (jobs[i].h > maxh) maxh = jobs[i].h;
+        alg += (double)jobs[i].w * jobs[i].h * (jobs[i].dst_inv ? 4.0 : 2.0);
+        if ((jobs[i].src_pitch & 15) || (jobs[i].dst_pitch & 3)) {
+            set_error("sauvola: pitches must be multiples of 16 (src) / 4 (dst)");
+            return MRCHIP_E_ARG;
+        }
+    }
+    if (ww <= 120) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    if (ww <= 360) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    return launch_k<16>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+}
+
+int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
+                   int ww, int wh, double k, double R, int flags) {
+    if (njobs == 1) return launch_sauvola_dev(ctx, s, jobs, nullptr, 1, ww, wh, k, R, flags);
+    set_error("launch_sauvola: multi-job launches go through launch_sauvola_dev");
+    return MRCHIP_E_ARG;
+}
+
+}  // namespace mrchip

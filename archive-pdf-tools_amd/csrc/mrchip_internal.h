@@ -1,0 +1,203 @@
+// Internal declarations shared by the libmrchip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mrchip.h"
+
+#define MRCHIP_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace mrchip {
+
+void set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            mrchip::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,              \
+                              hipGetErrorString(_e));                                    \
+            return MRCHIP_E_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define TRY(expr)                      \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != 0) return _r;        \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// All device images are pitched (pitch % 64 == 0) with PAD bytes of slack in
+// front of row 0 and behind the last row, so kernels may issue aligned dword
+// loads that straddle the row ends (the bytes are masked, never used).
+constexpr int PAD = 1024;
+
+struct DevBlock {
+    void *base = nullptr;   // hipMalloc'ed
+    size_t bytes = 0;
+    bool busy = false;
+};
+
+struct ProfEntry {
+    std::string name;
+    long long launches = 0;
+    double ms = 0;
+    double alg_bytes = 0;
+};
+
+struct ProfPending {
+    int entry;
+    hipEvent_t a, b;
+};
+
+constexpr int NSTREAMS = 4;
+
+}  // namespace mrchip
+
+struct mrchip_ctx {
+    int device = 0;
+    hipStream_t streams[mrchip::NSTREAMS] = {};
+    int next_stream = 0;
+    std::vector<mrchip::DevBlock> blocks;
+    // pinned staging for small control data (descriptors, results)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<mrchip::ProfEntry> prof_entries;
+    std::vector<mrchip::ProfPending> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    int cus = 0;
+    size_t hbm = 0;
+    char name[128] = {};
+};
+
+namespace mrchip {
+
+// caching device allocator (host-side bookkeeping only)
+int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out);
+void dev_free(mrchip_ctx *ctx, void *p);
+
+struct DevBuf {   // RAII for scratch inside an entry point
+    mrchip_ctx *ctx = nullptr;
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(mrchip_ctx *c, size_t bytes) {
+        release();
+        ctx = c;
+        return dev_alloc(c, bytes, &p);
+    }
+    void release() {
+        if (p) dev_free(ctx, p);
+        p = nullptr;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// pitched 8-bit image (c interleaved channels per pixel)
+struct Img8 {
+    DevBuf buf;
+    uint8_t *p = nullptr;  // row 0
+    int w = 0, h = 0, c = 1, pitch = 0;
+    int alloc(mrchip_ctx *ctx, int w_, int h_, int c_ = 1) {
+        w = w_; h = h_; c = c_;
+        pitch = round_up(w * c + 64, 64);
+        TRY(buf.alloc(ctx, (size_t)pitch * h + 2 * PAD));
+        p = buf.as<uint8_t>() + PAD;
+        return 0;
+    }
+    size_t bytes() const { return (size_t)pitch * h; }
+};
+
+int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
+int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
+
+// profiling hooks: prof_begin returns a token (<0: disabled)
+int prof_begin(mrchip_ctx *ctx, hipStream_t s, const char *name, double alg_bytes);
+void prof_end(mrchip_ctx *ctx, hipStream_t s, int token);
+int prof_resolve(mrchip_ctx *ctx);
+
+#define LAUNCH(ctx, stream, name, alg_bytes, ...)                                   \
+    do {                                                                            \
+        int _tok = mrchip::prof_begin(ctx, stream, name, (double)(alg_bytes));      \
+        __VA_ARGS__;                                                                \
+        mrchip::prof_end(ctx, stream, _tok);                                        \
+        HIP_TRY(hipGetLastError());                                                 \
+    } while (0)
+
+// ---- stage launchers (device pointers, asynchronous on `s`) -----------------
+
+// One Sauvola job = one image or crop treated as a standalone image.
+struct SauvolaJob {
+    const uint8_t *src;   // pixel (0,0) of the crop
+    int src_pitch;
+    int w, h;
+    uint8_t *dst;         // threshold output for the crop's pixel (0,0) (polarity A)
+    int dst_pitch;
+    uint8_t *dst_inv;     // optional: output for the 255-p image (polarity B), same pitch
+    unsigned int *counts; // optional: counts[0] += #ones(A), counts[1] += #ones(B)
+};
+
+enum SauvolaFlags {
+    SAUVOLA_INVERT = 1,   // store 1 for dark (mrc.threshold_image polarity)
+    SAUVOLA_OR = 2,       // dst |= result instead of dst = result
+};
+
+int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
+                   int ww, int wh, double k, double R, int flags);
+
+int launch_luma601(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int rgb_pitch,
+                   uint8_t *gray, int gray_pitch, int w, int h);
+
+// estimate_sigma of a crop; kind 0: u8 values as float32, kind 1: bool as float64.
+// Result (double) is written to *d_sigma (device) -- asynchronous.
+int launch_estimate_sigma(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch,
+                          int w, int h, int kind, double *d_sigma);
+
+int launch_gaussian_u8(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch,
+                       uint8_t *dst, int dpitch, int w, int h, const double *h_weights, int radius);
+
+int launch_denoise(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h,
+                   int mincnt, int n);
+
+int launch_optimise(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int mpitch,
+                    const uint8_t *img, int ipitch, uint8_t *out, int opitch,
+                    int w, int h, int c, int n, int invert_mask);
+
+// thumbnail on device images; out is tight-pitched [oh][ow*c] with pitch opitch
+int launch_thumbnail(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch, int w, int h,
+                     int c, int ow, int oh, uint8_t *dst, int dpitch);
+
+// hOCR: commit chosen thresholds into the mask in list order
+struct HocrBox {
+    int l, t, r, b;
+    int decision;            // 0 none, 1 thres, 2 thres_invert
+    const uint8_t *th;       // polarity A scratch (pixel (0,0) of the box)
+    const uint8_t *thi;      // polarity B scratch
+    int pitch;
+};
+int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int mpitch,
+                       const HocrBox *boxes, int nb);
+
+// host logic
+int thumbnail_size(int w, int h, int req_w, int req_h, int *ow, int *oh);
+int gaussian_weights_libm(double sigma, std::vector<double> &w);
+
+}  // namespace mrchip
+
+namespace mrchip {
+int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, const SauvolaJob *d_jobs,
+                       int njobs, int ww, int wh, double k, double R, int flags);
+}

@@ -1,0 +1,177 @@
+"""ctypes binding of libmrchip.so (include/mrchip.h)."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmrchip.so')
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+intp = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class MrchipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); every symbol include/mrchip.h declares
+SIGNATURES = {
+    'mrchip_abi_version': (C.c_int, []),
+    'mrchip_device_count': (C.c_int, []),
+    'mrchip_create': (vp, [C.c_int]),
+    'mrchip_destroy': (None, [vp]),
+    'mrchip_last_error': (C.c_char_p, []),
+    'mrchip_sync': (C.c_int, [vp]),
+    'mrchip_device_info': (C.c_int, [vp, C.c_char_p, C.c_int, intp, C.POINTER(C.c_size_t)]),
+    'mrchip_sauvola_u8': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    'mrchip_mask_denoise': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mrchip_optimise': (C.c_int, [vp, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mrchip_luma601': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int]),
+    'mrchip_estimate_sigma': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, f64p]),
+    'mrchip_estimate_noise_u8': (C.c_int, [vp, u8p, C.c_int, C.c_int, f64p]),
+    'mrchip_gaussian_u8': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, f64p, C.c_int]),
+    'mrchip_thumbnail_size': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, intp, intp]),
+    'mrchip_thumbnail': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p]),
+    'mrchip_window_for_dpi': (C.c_int, [C.c_int, C.c_double]),
+    'mrchip_hocr_mask': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p]),
+    'mrchip_page_create': (vp, [vp, C.c_int, C.c_int, C.c_int]),
+    'mrchip_page_destroy': (None, [vp]),
+    'mrchip_page_upload': (C.c_int, [vp, u8p]),
+    'mrchip_page_mask_begin': (C.c_int, [vp, i32p, C.c_int, C.c_int]),
+    'mrchip_page_sigma': (C.c_int, [vp, f64p]),
+    'mrchip_page_mask_finish': (C.c_int, [vp, f64p, C.c_int, C.c_int]),
+    'mrchip_page_download_mask': (C.c_int, [vp, u8p]),
+    'mrchip_page_layer': (C.c_int, [vp, C.c_int, C.c_double, intp, intp, intp]),
+    'mrchip_page_download_layer': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_page_sync': (C.c_int, [vp]),
+    'mrchip_page_box_decisions': (C.c_int, [vp, i32p, C.c_int]),
+    'mrchip_page_device_ptrs': (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                          C.POINTER(vp), C.POINTER(vp)]),
+    'mrchip_prof_enable': (C.c_int, [vp, C.c_int]),
+    'mrchip_prof_reset': (C.c_int, [vp]),
+    'mrchip_prof_count': (C.c_int, [vp]),
+    'mrchip_prof_get': (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), f64p, f64p]),
+}
+
+
+def load():
+    """Load libmrchip.so; raises MrchipError when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise MrchipError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"`'
+                                  ' (make -C archive-pdf-tools_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().mrchip_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise MrchipError('%s failed (%d): %s' % (what or 'libmrchip call', rc, last_error()))
+
+
+class Context:
+    """One HIP context (device + streams + scratch) -- mrchip_create/mrchip_destroy."""
+
+    def __init__(self, device=0):
+        lib = load()
+        self._h = lib.mrchip_create(device)
+        if not self._h:
+            raise MrchipError('mrchip_create(%d): %s' % (device, last_error()))
+        self.device = device
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise MrchipError('context destroyed')
+        return self._h
+
+    def close(self):
+        if self._h:
+            load().mrchip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(load().mrchip_sync(self.handle), 'mrchip_sync')
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus = C.c_int()
+        hbm = C.c_size_t()
+        check(load().mrchip_device_info(self.handle, name, 128, C.byref(cus), C.byref(hbm)))
+        return {'name': name.value.decode(), 'cus': cus.value, 'hbm_bytes': hbm.value}
+
+    def prof_enable(self, on=True):
+        check(load().mrchip_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(load().mrchip_prof_reset(self.handle))
+
+    def prof_report(self):
+        lib = load()
+        n = lib.mrchip_prof_count(self.handle)
+        if n < 0:
+            check(n, 'mrchip_prof_count')
+        out = {}
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            launches = C.c_longlong()
+            ms = C.c_double()
+            ab = C.c_double()
+            check(lib.mrchip_prof_get(self.handle, i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
+            out[name.value.decode()] = {'launches': launches.value, 'ms': ms.value, 'alg_bytes': ab.value}
+        return out
+
+
+_tls = threading.local()
+
+
+def default_context():
+    """Per-thread default context on MRCHIP_DEVICE (default 0)."""
+    ctx = getattr(_tls, 'ctx', None)
+    if ctx is None:
+        ctx = Context(int(os.environ.get('MRCHIP_DEVICE', '0') or 0))
+        _tls.ctx = ctx
+    return ctx
+
+
+def mrchip_visible_devices():
+    return load().mrchip_device_count()
+
+
+def as_u8(a, name='array'):
+    """C-contiguous uint8 view of a uint8/bool array (copy only if needed)."""
+    a = np.asarray(a)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    if a.dtype != np.uint8:
+        raise ValueError("Buffer dtype mismatch, expected 'UINT8DTYPE_t' but got '%s' (%s)" % (a.dtype, name))
+    return np.ascontiguousarray(a)
+
+
+def ptr(a, t=u8p):
+    return a.ctypes.data_as(t)

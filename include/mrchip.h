@@ -1,0 +1,158 @@
+/*
+ * mrchip.h -- C ABI of libmrchip.so: the MI355X (gfx950) implementation of the
+ * archive-pdf-tools MRC page-decomposition hot path.
+ *
+ * Every entry point replaces one interface of the reference (cited per
+ * function as file:line under /root/reference).  Plain pointers and sizes only.
+ * All functions return 0 on success or a negative MRCHIP_E_* code;
+ * mrchip_last_error() returns a thread-local message.  There is NO CPU
+ * fallback behind any of these: without a usable HIP device every call fails.
+ *
+ * Buffers passed to the "host-buffer" entry points are ordinary host memory
+ * (the numpy arrays the reference passes to its Cython modules); the library
+ * stages them through pinned memory.  The "page" entry points keep a page
+ * resident on the device between the three yields of
+ * mrc.create_mrc_hocr_components so that pixels cross PCIe once.
+ *
+ * Threading: a context owns its HIP streams and scratch; use one context per
+ * thread (the reference is single-threaded and re-entrant).
+ */
+#ifndef MRCHIP_H
+#define MRCHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCHIP_ABI_VERSION 1
+
+enum {
+    MRCHIP_OK = 0,
+    MRCHIP_E_HIP = -1,        /* HIP runtime error (see mrchip_last_error) */
+    MRCHIP_E_ARG = -2,        /* invalid argument */
+    MRCHIP_E_UNSUPPORTED = -3,/* parameter outside the implemented range */
+    MRCHIP_E_NOMEM = -4,
+    MRCHIP_E_STATE = -5       /* call out of order on a page handle */
+};
+
+typedef struct mrchip_ctx mrchip_ctx;
+typedef struct mrchip_page mrchip_page;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int mrchip_abi_version(void);
+int mrchip_device_count(void);
+/* One context per (thread, device).  NULL on failure. */
+mrchip_ctx *mrchip_create(int device);
+void mrchip_destroy(mrchip_ctx *ctx);
+const char *mrchip_last_error(void);
+int mrchip_sync(mrchip_ctx *ctx);
+/* Device name / CU count of the context's device (for reports). */
+int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes);
+
+/* ---- cython/sauvola.pyx -------------------------------------------------- */
+/* sauvola.binarise_sauvola(in_arr, out_arr, width, height, window_width,
+ * window_height, k, R) -- cython/sauvola.pyx:29-222.  in/out are flat
+ * row-major uint8[w*h]; out = 1 for bright/background, 0 for dark (pyx:153).
+ * invert != 0 stores the complement instead, i.e. mrc.threshold_image's
+ * np.invert (mrc.py:85) fused.  Returns 0 like the reference (pyx:222). */
+int mrchip_sauvola_u8(mrchip_ctx *ctx, const uint8_t *in, uint8_t *out, int w, int h,
+                      int window_w, int window_h, double k, double R, int invert);
+
+/* ---- cython/optimiser.pyx ------------------------------------------------ */
+/* optimiser.fast_mask_denoise(mask, width, height, mincnt, n_size) --
+ * cython/optimiser.pyx:436-472.  In place on uint8/bool[h][w]. */
+int mrchip_mask_denoise(mrchip_ctx *ctx, uint8_t *mask, int w, int h, int mincnt, int n_size);
+
+/* optimiser.optimise_gray2 / optimise_rgb2 (and the slow optimise_gray /
+ * optimise_rgb, identical results) -- cython/optimiser.pyx:153-273, 280-429,
+ * 22-146.  mask uint8/bool[h][w]; img/out uint8[h][w][channels] interleaved,
+ * channels 1 or 3.  invert_mask != 0 uses (mask ^ 1), the reference's
+ * mask_inv (mrc.py:439) fused. */
+int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const uint8_t *img, uint8_t *out,
+                    int w, int h, int channels, int n_size, int invert_mask);
+
+/* ---- third-party stages reached from internetarchivepdf/mrc.py ----------- */
+/* PIL Image.convert('L') of an RGB image -- mrc.py:361. */
+int mrchip_luma601(mrchip_ctx *ctx, const uint8_t *rgb, uint8_t *gray, int w, int h);
+
+/* mean_estimate_sigma(arr) = np.mean(skimage estimate_sigma(arr)) --
+ * mrc.py:52-55.  kind 0: arr is a uint8 image taken as float32 values (the
+ * grayimgf of mrc.py:372); kind 1: arr is a bool array (mrc.py:253-254,
+ * PyWavelets' float64 path).  stride in elements. */
+int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int stride, int w, int h,
+                          int kind, double *sigma);
+/* mrc.estimate_noise(imgf) on float32(gray) -- mrc.py:273-296. */
+int mrchip_estimate_noise_u8(mrchip_ctx *ctx, const uint8_t *gray, int w, int h, double *sigma);
+
+/* scipy.ndimage.gaussian_filter(float32(gray), sigma).astype(uint8) --
+ * mrc.py:311 + 325.  weights = the 2*radius+1 float64 table scipy builds on
+ * the host (filters.py _gaussian_kernel1d); NULL = build it here with libm. */
+int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *out, int w, int h,
+                       double sigma, const double *weights, int radius);
+
+/* PIL Image.thumbnail((req_w, req_h)) with defaults (BICUBIC, reducing_gap=2)
+ * -- mrc.py:422-428, 456-462.  mrchip_thumbnail_size is the host-side size
+ * rule (returns 1 if the image changes, 0 if left untouched). */
+int mrchip_thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h);
+int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels,
+                     int req_w, int req_h, uint8_t *out /* out_w*out_h*channels */);
+
+/* ---- internetarchivepdf/mrc.py ------------------------------------------- */
+/* mrc.threshold_image window rule -- mrc.py:68-75. */
+int mrchip_window_for_dpi(int has_dpi, double dpi);
+
+/* mrc.create_hocr_mask pixel work -- mrc.py:223-266 -- for boxes that passed
+ * the text/confidence/geometry filter (mrc.py:198-221, host logic).
+ * boxes = nb x {left, top, right, bottom}, committed in list order.
+ * decisions (optional, nb): 0 none, 1 thres, 2 thres_invert. */
+int mrchip_hocr_mask(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *mask, int w, int h,
+                     const int32_t *boxes, int nb, int window, int32_t *decisions);
+
+/* ---- device-resident page: mrc.create_mrc_hocr_components (mrc.py:334-471) */
+mrchip_page *mrchip_page_create(mrchip_ctx *ctx, int w, int h, int channels);
+void mrchip_page_destroy(mrchip_page *pg);
+/* uint8[h][w][channels] host image -> device (asynchronous on the page's stream) */
+int mrchip_page_upload(mrchip_page *pg, const uint8_t *img);
+/* Phase A (enqueue only): luma, both hOCR-box thresholds + counts, noise estimate. */
+int mrchip_page_mask_begin(mrchip_page *pg, const int32_t *boxes, int nb, int window);
+/* Waits for phase A; returns sigma_est (mrc.py:305).  The caller (host, like
+ * scipy) builds the Gaussian table for sigma_est*0.1 when sigma_est > 1. */
+int mrchip_page_sigma(mrchip_page *pg, double *sigma_est);
+/* Phase B (enqueue only): box decisions + commit, blur, Sauvola k=0.34, OR,
+ * fast denoise.  weights/radius as in mrchip_gaussian_u8 (ignored unless
+ * sigma_est > 1). */
+int mrchip_page_mask_finish(mrchip_page *pg, const double *weights, int radius, int denoise_fast);
+/* first yield: bool[h][w] */
+int mrchip_page_download_mask(mrchip_page *pg, uint8_t *mask);
+/* second / third yield (enqueue only): optimise (fg: n=3 on mask; bg: n=10 on
+ * the inverted mask) + optional thumbnail.  downsample <= 0: none.
+ * *too_small = 1 reproduces 'too-small-to-downsample' (mrc.py:429-431). */
+int mrchip_page_layer(mrchip_page *pg, int is_bg, double downsample, int *out_w, int *out_h,
+                      int *too_small);
+int mrchip_page_download_layer(mrchip_page *pg, int is_bg, uint8_t *out);
+int mrchip_page_sync(mrchip_page *pg);
+/* decisions of the hOCR boxes after mask_finish (diagnostics / tests) */
+int mrchip_page_box_decisions(mrchip_page *pg, int32_t *decisions, int nb);
+/* device pointers for zero-copy consumers (mask [h][pitch], layer tight) */
+int mrchip_page_device_ptrs(mrchip_page *pg, void **img, void **mask, size_t *mask_pitch,
+                            void **fg, void **bg);
+
+/* ---- measurement --------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the stream each kernel is launched on.
+ * enable: 0 off, 1 on.  Kernels are named as in the kernel trace. */
+int mrchip_prof_enable(mrchip_ctx *ctx, int enable);
+int mrchip_prof_reset(mrchip_ctx *ctx);
+/* Resolves pending events (synchronises).  Returns the number of distinct
+ * kernels; index i in [0,n): name, launches, total milliseconds,
+ * algorithmic bytes accumulated over those launches. */
+int mrchip_prof_count(mrchip_ctx *ctx);
+int mrchip_prof_get(mrchip_ctx *ctx, int i, char *name, int name_len, long long *launches,
+                    double *total_ms, double *alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRCHIP_H */

@@ -1,0 +1,89 @@
+"""GPU parity: HIP Sauvola (through the C ABI) vs the oracle and the reference goldens."""
+import numpy as np
+import pytest
+
+import mrc_oracle as O
+from mrchip import sauvola, synth
+from helpers import kernel_cases, unpack, load_digests, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(img, ww, wh, k, R=128.0):
+    h, w = img.shape
+    out = np.empty(h * w, dtype=np.uint8)
+    assert sauvola.binarise_sauvola(img.reshape(-1), out, w, h, ww, wh, k, R) == 0
+    return out.reshape(h, w)
+
+
+def run_cpu(img, ww, wh, k, R=128.0):
+    h, w = img.shape
+    out = np.empty(h * w, dtype=np.uint8)
+    O.binarise_sauvola(img.reshape(-1), out, w, h, ww, wh, k, R)
+    return out.reshape(h, w)
+
+
+def test_golden_vectors():
+    z, cases = kernel_cases('sauvola')
+    for _, i, h, w, ww, wh, k in cases:
+        got = run_gpu(z['sau_in_%d' % i], ww, wh, k)
+        exp = unpack(z['sau_out_%d' % i], w)
+        assert np.array_equal(got.astype(bool), exp), (i, h, w, ww, wh, k, int((got.astype(bool) != exp).sum()))
+
+
+@pytest.mark.parametrize('h,w,ww,wh,k', [
+    (300, 517, 51, 51, 0.34), (300, 517, 51, 51, 0.1), (257, 1031, 31, 31, 0.34), (100, 2000, 101, 101, 0.34),
+    (400, 300, 91, 91, 0.34), (64, 64, 30, 30, -0.2), (37, 1200, 51, 51, 0.1), (3, 3, 51, 51, 0.34),
+    (1, 700, 51, 51, 0.34), (700, 1, 51, 51, 0.34), (200, 900, 151, 51, 0.34), (150, 2100, 401, 101, 0.2),
+    (90, 333, 2, 2, 0.34), (90, 333, 1, 1, 0.34), (128, 4000, 51, 51, 0.34), (513, 209, 51, 7, 0.5),
+])
+def test_random_vs_oracle(h, w, ww, wh, k):
+    rng = np.random.RandomState(h * 7919 + w)
+    for kind in range(3):
+        if kind == 0:
+            img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        elif kind == 1:
+            img = np.clip(rng.normal(140, 3, (h, w)), 0, 255).astype(np.uint8)    # near-flat: decision boundary
+        else:
+            img = synth.synth_page(w, h, 1, seed=h + w, noise_sigma=5.0, line_div=max(2, h // 30))[0]
+        got, exp = run_gpu(img, ww, wh, k), run_cpu(img, ww, wh, k)
+        assert np.array_equal(got, exp), (kind, int((got != exp).sum()))
+
+
+def test_constant_images():
+    for v in (0, 1, 127, 255):
+        img = np.full((120, 300), v, dtype=np.uint8)
+        assert np.array_equal(run_gpu(img, 51, 51, 0.34), run_cpu(img, 51, 51, 0.34)), v
+
+
+def test_bool_out_array_and_return_value():
+    img = synth.kat_pattern(128, 96)
+    out = np.ndarray(96 * 128, dtype=bool)
+    assert sauvola.binarise_sauvola(img.reshape(-1), out, 128, 96, 31, 31, 0.34, 128) == 0
+    assert sha(out)[:16] == 'eea1434f2c20e76c' and int(out.sum()) == 10992
+
+
+def test_unsupported_window_is_an_error_not_a_fallback():
+    from mrchip._lib import MrchipError
+    img = np.zeros((300, 300), np.uint8)
+    out = np.empty(300 * 300, np.uint8)
+    with pytest.raises(MrchipError):
+        sauvola.binarise_sauvola(img.reshape(-1), out, 300, 300, 301, 301, 0.34, 128.0)
+
+
+def test_config_sizes_digest_and_property():
+    d = load_digests()
+    # config 1: 1200x1600 gray, window 31 -- digest made by the reference
+    img = synth.synth_page(1200, 1600, 1, seed=101, noise_sigma=6.0)[0]
+    assert sha(img) == d['c1_threshold']['in']
+    got = run_gpu(img, 31, 31, 0.34)
+    assert sha(~got.astype(bool)) == d['c1_threshold']['out']
+    # config 3 shape 3300x4600, window 51: digest + full comparison with the oracle
+    img = synth.synth_page(3300, 4600, 1, seed=303, noise_sigma=6.0)[0]
+    assert sha(img) == d['c3_threshold']['in']
+    got = run_gpu(img, 51, 51, 0.34)
+    assert sha(~got.astype(bool)) == d['c3_threshold']['out']
+    # size-independent property: the image 255-p under k2-symmetric formula is NOT the complement,
+    # but translating the page by a multiple of the tile leaves interior results unchanged
+    sub = run_gpu(np.ascontiguousarray(img[1000:2000, 500:2500]), 51, 51, 0.34)
+    assert np.array_equal(sub[26:-26, 26:-26], got[1026:1974, 526:2474])
