@@ -53,3 +53,130 @@ MRCHIP_EXPORT int mrchip_luma601(mrchip_ctx *ctx, const uint8_t *rgb, uint8_t *g
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
+
+MRCHIP_EXPORT int mrchip_mask_denoise(mrchip_ctx *ctx, uint8_t *mask, int w, int h, int mincnt, int n_size) {
+    CHECK_CTX(ctx);
+    if (!mask || w < 0 || h < 0) { set_error("mask_denoise: bad arguments"); return MRCHIP_E_ARG; }
+    if (w == 0 || h == 0) return 0;
+    hipStream_t s = ctx->streams[0];
+    Img8 m;
+    DevBuf bits;
+    TRY(m.alloc(ctx, w, h));
+    TRY(bits.alloc(ctx, denoise_scratch_bytes(w, h)));
+    TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
+    TRY(launch_denoise_scratch(ctx, s, m.p, m.pitch, w, h, mincnt, n_size, bits.as<unsigned>()));
+    TRY(download_2d(s, mask, w, m.p, m.pitch, w, h));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const uint8_t *img, uint8_t *out,
+                                  int w, int h, int channels, int n_size, int invert_mask) {
+    CHECK_CTX(ctx);
+    if (!mask || !img || !out || w < 0 || h < 0) { set_error("optimise: bad arguments"); return MRCHIP_E_ARG; }
+    if (channels != 1 && channels != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
+    if (w == 0 || h == 0) return 0;
+    hipStream_t s = ctx->streams[0];
+    Img8 m, i, o;
+    TRY(m.alloc(ctx, w, h));
+    TRY(i.alloc(ctx, w, h, channels));
+    TRY(o.alloc(ctx, w, h, channels));
+    TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
+    TRY(upload_2d(s, i.p, i.pitch, img, w * channels, w * channels, h));
+    TRY(launch_optimise(ctx, s, m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, channels, n_size, invert_mask));
+    TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int stride, int w, int h, int kind,
+                                        double *sigma) {
+    CHECK_CTX(ctx);
+    if (!arr || !sigma || w <= 0 || h <= 0 || stride < w || (kind != 0 && kind != 1)) {
+        set_error("estimate_sigma: bad arguments");
+        return MRCHIP_E_ARG;
+    }
+    hipStream_t s = ctx->streams[0];
+    Img8 m;
+    DevBuf scratch, res;
+    TRY(m.alloc(ctx, w, h));
+    TRY(scratch.alloc(ctx, sigma_scratch_bytes(w, h, kind)));
+    TRY(res.alloc(ctx, 64));
+    TRY(upload_2d(s, m.p, m.pitch, arr, stride, w, h));
+    TRY(launch_estimate_sigma_scratch(ctx, s, m.p, m.pitch, w, h, kind, res.as<double>(), scratch.p));
+    HIP_TRY(hipMemcpyAsync(sigma, res.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_estimate_noise_u8(mrchip_ctx *ctx, const uint8_t *gray, int w, int h, double *sigma) {
+    if (!gray || w <= 0 || h <= 0) { set_error("estimate_noise: bad arguments"); return MRCHIP_E_ARG; }
+    int hs = (int)(h / 2.0 - h / 4.0), he = (int)(h / 2.0 + h / 4.0);      // mrc.py:282-285
+    int ws = (int)(w / 2.0 - w / 4.0), we = (int)(w / 2.0 + w / 4.0);
+    if (he == 0 || we == 0) { hs = 0; he = h; ws = 0; we = w; }           // mrc.py:288-292
+    return mrchip_estimate_sigma(ctx, gray + (size_t)hs * w + ws, w, we - ws, he - hs, 0, sigma);
+}
+
+MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *out, int w, int h, double sigma,
+                                     const double *weights, int radius) {
+    CHECK_CTX(ctx);
+    if (!gray || !out || w <= 0 || h <= 0 || !(sigma > 0)) { set_error("gaussian: bad arguments"); return MRCHIP_E_ARG; }
+    std::vector<double> wl;
+    if (!weights) {
+        TRY(gaussian_weights_libm(sigma, wl));
+        weights = wl.data();
+        radius = (int)(wl.size() / 2);
+    } else if (radius != (int)(4.0 * sigma + 0.5)) {
+        set_error("gaussian: radius %d does not match sigma %.17g (scipy: int(4*sigma+0.5))", radius, sigma);
+        return MRCHIP_E_ARG;
+    }
+    hipStream_t s = ctx->streams[0];
+    Img8 a, b;
+    DevBuf tmp;
+    const int tp = round_up(w, 16);
+    TRY(a.alloc(ctx, w, h));
+    TRY(b.alloc(ctx, w, h));
+    TRY(tmp.alloc(ctx, (size_t)tp * h * sizeof(float)));
+    TRY(upload_2d(s, a.p, a.pitch, gray, w, w, h));
+    TRY(launch_gaussian_u8_scratch(ctx, s, a.p, a.pitch, b.p, b.pitch, w, h, weights, radius, tmp.as<float>(), tp));
+    TRY(download_2d(s, out, w, b.p, b.pitch, w, h));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h) {
+    if (w <= 0 || h <= 0 || req_w <= 0 || req_h <= 0 || !out_w || !out_h) { set_error("thumbnail_size: bad arguments"); return MRCHIP_E_ARG; }
+    return thumbnail_size(w, h, req_w, req_h, out_w, out_h);
+}
+
+MRCHIP_EXPORT int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels, int req_w, int req_h,
+                                   uint8_t *out) {
+    CHECK_CTX(ctx);
+    if (!in || !out || w <= 0 || h <= 0 || req_w <= 0 || req_h <= 0 || (channels != 1 && channels != 3)) {
+        set_error("thumbnail: bad arguments");
+        return MRCHIP_E_ARG;
+    }
+    ThumbPlan p;
+    TRY(ThumbPlan_build(p, w, h, channels, req_w, req_h));
+    if (!p.changed) { memcpy(out, in, (size_t)w * h * channels); return 0; }
+    hipStream_t s = ctx->streams[0];
+    Img8 src;
+    DevBuf dst, s1, s2, tab;
+    const int c = channels;
+    TRY(src.alloc(ctx, w, h, c));
+    TRY(dst.alloc(ctx, (size_t)p.ow * p.oh * c + 256));
+    TRY(s1.alloc(ctx, (size_t)p.rw * p.rh * c + 256));
+    TRY(s2.alloc(ctx, (size_t)p.ow * p.rh * c + 256));
+    TRY(tab.alloc(ctx, ThumbPlan_table_bytes(p)));
+    int32_t *d = tab.as<int32_t>();
+    HIP_TRY(hipMemcpyAsync(d, p.bh_.data(), p.bh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bh_.size();
+    HIP_TRY(hipMemcpyAsync(d, p.kh_.data(), p.kh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.kh_.size();
+    HIP_TRY(hipMemcpyAsync(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bv_.size();
+    HIP_TRY(hipMemcpyAsync(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice, s));
+    TRY(upload_2d(s, src.p, src.pitch, in, w * c, w * c, h));
+    TRY(launch_thumbnail_plan(ctx, s, p, src.p, src.pitch, dst.as<uint8_t>(), p.ow * c, tab.as<int32_t>(),
+                              s1.as<uint8_t>(), s2.as<uint8_t>()));
+    HIP_TRY(hipMemcpyAsync(out, dst.p, (size_t)p.ow * p.oh * c, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}

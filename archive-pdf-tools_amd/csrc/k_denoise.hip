@@ -1,0 +1,317 @@
+// fast_mask_denoise (reference: cython/optimiser.pyx:436-472) for gfx950.
+//
+// The reference sweeps the mask in raster order IN PLACE: a set pixel survives
+// iff at least `mincnt` OTHER pixels of its (2n+1)^2 window are set, where the
+// neighbours earlier in raster order are already updated.  The result is the
+// unique solution f of
+//     f(p) = m(p) & ( sum_{q earlier} f(q) + sum_{q later} m(q) >= mincnt )
+// on the inner rectangle [n,H-n) x [n,W-n); everything else keeps m.
+//
+// Fast path (n=2, mincnt=4 -- the only call site, mrc.py:388): bit-packed and
+// bit-sliced.  pack: bytes -> 1 bit/pixel (32 px per dword).  solve: ONE wave
+// walks the page top to bottom; each lane holds KW consecutive 32-pixel words of
+// a row, so a wave spans 2048*KW columns entirely in registers.  Per row the
+// neighbour count is built with carry-save adders on whole words (5-tap
+// horizontal sums of the two final rows above and the two original rows below,
+// saturating at 4), pixels are classified as keep / drop / "needs one or two of
+// its two left neighbours", and the left-to-right recurrence inside the row is
+// resolved by a monotone word-parallel iteration (funnel shifts + one lane
+// shuffle per sweep) that stops when no bit changes -- a few sweeps on text,
+// chain-length sweeps on a 1-px rule.  Rows are inherently sequential (row y
+// needs the FINAL rows y-1, y-2), pages are independent: a batch runs one wave
+// per page.  unpack: bits -> bytes.
+//
+// General (n, mincnt): byte-domain Jacobi sweeps to the same unique fixpoint.
+//
+// Algorithmic bytes: 2*w*h per call.
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+// ---- pack / unpack ----------------------------------------------------------
+__device__ __forceinline__ unsigned nz_nibble(unsigned d) {
+    unsigned t = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;   // 0x80 per nonzero byte
+    t >>= 7;
+    return (t * 0x01020408u) >> 24 & 0xFu;
+}
+
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int pitch, int w, int h,
+                                                        unsigned *bits, int wpr /* words per row */) {
+    const int y = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= wpr) return;
+    const uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
+    unsigned word = 0;
+    if (j * 32 + 32 <= w) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(row);
+        uint4 a = p[0], b = p[1];
+        word = nz_nibble(a.x) | nz_nibble(a.y) << 4 | nz_nibble(a.z) << 8 | nz_nibble(a.w) << 12 |
+               nz_nibble(b.x) << 16 | nz_nibble(b.y) << 20 | nz_nibble(b.z) << 24 | nz_nibble(b.w) << 28;
+    } else {
+        for (int i = 0; j * 32 + i < w; i++) word |= (row[i] ? 1u : 0u) << i;
+    }
+    bits[(size_t)y * wpr + j] = word;
+}
+
+__device__ __forceinline__ unsigned spread_nibble(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
+
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned *bits, int wpr, uint8_t *mask, int pitch,
+                                                          int w, int h) {
+    const int y = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= wpr) return;
+    const unsigned word = bits[(size_t)y * wpr + j];
+    uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
+    if (j * 32 + 32 <= w) {
+        uint4 a, b;
+        a.x = spread_nibble(word & 0xF); a.y = spread_nibble((word >> 4) & 0xF);
+        a.z = spread_nibble((word >> 8) & 0xF); a.w = spread_nibble((word >> 12) & 0xF);
+        b.x = spread_nibble((word >> 16) & 0xF); b.y = spread_nibble((word >> 20) & 0xF);
+        b.z = spread_nibble((word >> 24) & 0xF); b.w = spread_nibble(word >> 28);
+        reinterpret_cast<uint4 *>(row)[0] = a;
+        reinterpret_cast<uint4 *>(row)[1] = b;
+    } else {
+        for (int i = 0; j * 32 + i < w; i++) row[i] = (word >> i) & 1u;
+    }
+}
+
+// ---- bit-sliced sequential solve (n = 2, mincnt = 4) --------------------------
+// saturating 3-plane counter: value = b0 + 2*b1, hi = "value >= 4" (sticky)
+struct Sat { unsigned b0, b1, hi; };
+
+__device__ __forceinline__ Sat sat_add(const Sat &a, const Sat &b) {
+    Sat r;
+    unsigned k0 = a.b0 & b.b0;
+    r.b0 = a.b0 ^ b.b0;
+    unsigned x1 = a.b1 ^ b.b1;
+    r.b1 = x1 ^ k0;
+    unsigned k1 = (a.b1 & b.b1) | (k0 & x1);
+    r.hi = a.hi | b.hi | k1;
+    return r;
+}
+
+// value at pixel x+d brought to bit position x; L = previous word (lower x), R = next word
+__device__ __forceinline__ unsigned sh_p1(unsigned cur, unsigned R) { return __builtin_amdgcn_alignbit(R, cur, 1); }
+__device__ __forceinline__ unsigned sh_p2(unsigned cur, unsigned R) { return __builtin_amdgcn_alignbit(R, cur, 2); }
+__device__ __forceinline__ unsigned sh_m1(unsigned cur, unsigned L) { return __builtin_amdgcn_alignbit(cur, L, 31); }
+__device__ __forceinline__ unsigned sh_m2(unsigned cur, unsigned L) { return __builtin_amdgcn_alignbit(cur, L, 30); }
+
+template <int KW>
+struct Row { unsigned w[KW]; };
+
+template <int KW>
+__device__ __forceinline__ void neighbours(const Row<KW> &r, int lane, unsigned (&L)[KW], unsigned (&R)[KW]) {
+    unsigned up = __shfl_up(r.w[KW - 1], 1);      // last word of the previous lane
+    unsigned dn = __shfl_down(r.w[0], 1);         // first word of the next lane
+    if (lane == 0) up = 0;
+    if (lane == 63) dn = 0;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        L[k] = k > 0 ? r.w[k - 1] : up;
+        R[k] = k < KW - 1 ? r.w[k + 1] : dn;
+    }
+}
+
+// 5-tap horizontal sum (x-2..x+2) of a bit row -> Sat (0..5: b0, b1, hi=fours)
+template <int KW>
+__device__ __forceinline__ void h5(const Row<KW> &r, int lane, Sat (&out)[KW]) {
+    unsigned L[KW], R[KW];
+    neighbours<KW>(r, lane, L, R);
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        unsigned c = r.w[k];
+        unsigned a = sh_m2(c, L[k]), b = sh_m1(c, L[k]), d = sh_p1(c, R[k]), e = sh_p2(c, R[k]);
+        unsigned ab = a ^ b;
+        unsigned s1 = ab ^ c;
+        unsigned c1 = (a & b) | (c & ab);
+        unsigned s2 = d ^ e, c2 = d & e;
+        unsigned c3 = s1 & s2;
+        out[k].b0 = s1 ^ s2;
+        unsigned t = c1 ^ c2;
+        out[k].b1 = t ^ c3;
+        out[k].hi = (c1 & c2) | (c3 & t);
+    }
+}
+
+template <int KW>
+__device__ __forceinline__ Row<KW> load_row(const unsigned *bits, int wpr, int y, int h, int lane) {
+    Row<KW> r;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        int j = lane * KW + k;
+        r.w[k] = (y >= 0 && y < h && j < wpr) ? bits[(size_t)y * wpr + j] : 0u;
+    }
+    return r;
+}
+
+template <int KW>
+__global__ __launch_bounds__(64) void denoise_seq_kernel(unsigned *bits, int wpr, int w, int h) {
+    // in place: row y is overwritten with its final value after rows y+1, y+2 have been read
+    const int lane = threadIdx.x;
+    constexpr int n = 2;
+    if (h <= 2 * n || w <= 2 * n) return;
+    // inner-column mask: columns [n, w-n)
+    unsigned inner[KW];
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        int x0 = (lane * KW + k) * 32;
+        unsigned m = 0;
+        for (int i = 0; i < 32; i++) {
+            int x = x0 + i;
+            if (x >= n && x < w - n) m |= 1u << i;
+        }
+        inner[k] = m;
+    }
+    // rows 0,1 are final as they are
+    Row<KW> f2 = load_row<KW>(bits, wpr, 0, h, lane);
+    Row<KW> f1 = load_row<KW>(bits, wpr, 1, h, lane);
+    Row<KW> m0 = load_row<KW>(bits, wpr, 2, h, lane);
+    Row<KW> m1 = load_row<KW>(bits, wpr, 3, h, lane);
+    Row<KW> m2 = load_row<KW>(bits, wpr, 4, h, lane);
+    // prefetch ring for the incoming original rows
+    constexpr int PF = 4;
+    Row<KW> pf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) pf[i] = load_row<KW>(bits, wpr, 5 + i, h, lane);
+
+    Sat hf2[KW], hf1[KW], hm1[KW], hm2[KW];
+    h5<KW>(f2, lane, hf2);
+    h5<KW>(f1, lane, hf1);
+    h5<KW>(m1, lane, hm1);
+    h5<KW>(m2, lane, hm2);
+
+    for (int y = n; y < h - n; y++) {
+        // static part of the count: finals above, originals below, originals to the right
+        unsigned always[KW], t1[KW], t2[KW], fixed[KW], upd[KW];
+        {
+            unsigned L[KW], R[KW];
+            neighbours<KW>(m0, lane, L, R);
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                Sat s = sat_add(sat_add(hf2[k], hf1[k]), sat_add(hm1[k], hm2[k]));
+                unsigned d = sh_p1(m0.w[k], R[k]), e = sh_p2(m0.w[k], R[k]);
+                Sat rr; rr.b0 = d ^ e; rr.b1 = d & e; rr.hi = 0;
+                s = sat_add(s, rr);
+                always[k] = s.hi;                        // static count >= 4
+                t1[k] = ~s.hi & s.b1 & s.b0;             // == 3: needs one more
+                t2[k] = ~s.hi & s.b1 & ~s.b0;            // == 2: needs both left neighbours
+                upd[k] = m0.w[k] & inner[k];
+                fixed[k] = m0.w[k] & ~inner[k];
+            }
+        }
+        // left-to-right recurrence: monotone iteration from the upper bound f = m0
+        Row<KW> f = m0;
+        for (;;) {
+            unsigned up = __shfl_up(f.w[KW - 1], 1);
+            if (lane == 0) up = 0;
+            unsigned changed = 0;
+            Row<KW> g;
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                unsigned Lw = k > 0 ? f.w[k - 1] : up;
+                unsigned a = sh_m1(f.w[k], Lw), b = sh_m2(f.w[k], Lw);
+                unsigned nf = fixed[k] | (upd[k] & (always[k] | (t1[k] & (a | b)) | (t2[k] & a & b)));
+                changed |= nf ^ f.w[k];
+                g.w[k] = nf;
+            }
+            f = g;
+            if (!__any(changed != 0)) break;
+        }
+        // store the final row
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            int j = lane * KW + k;
+            if (j < wpr) bits[(size_t)y * wpr + j] = f.w[k];
+        }
+        // advance the window
+#pragma unroll
+        for (int k = 0; k < KW; k++) { hf2[k] = hf1[k]; }
+        h5<KW>(f, lane, hf1);
+#pragma unroll
+        for (int k = 0; k < KW; k++) { hm1[k] = hm2[k]; }
+        m0 = m1; m1 = m2; m2 = pf[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; i++) pf[i] = pf[i + 1];
+        pf[PF - 1] = load_row<KW>(bits, wpr, y + 3 + PF, h, lane);
+        h5<KW>(m2, lane, hm2);
+    }
+}
+
+// ---- general (n, mincnt): byte-domain Jacobi to the unique fixpoint ------------
+__global__ __launch_bounds__(256) void denoise_jacobi_kernel(const uint8_t *orig, const uint8_t *cur, uint8_t *next,
+                                                             int pitch, int w, int h, int mincnt, int n,
+                                                             int *changed) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const size_t idx = (size_t)y * pitch + x;
+    uint8_t o = orig[idx] ? 1 : 0;
+    uint8_t v = o;
+    if (o && x >= n && x < w - n && y >= n && y < h - n) {
+        int cnt = 0;
+        for (int dy = -n; dy <= n; dy++)
+            for (int dx = -n; dx <= n; dx++) {
+                if (dy == 0 && dx == 0) continue;
+                const bool earlier = (dy < 0) || (dy == 0 && dx < 0);
+                const size_t q = (size_t)(y + dy) * pitch + (x + dx);
+                cnt += earlier ? (cur[q] ? 1 : 0) : (orig[q] ? 1 : 0);
+            }
+        v = cnt >= mincnt ? 1 : 0;
+    }
+    if (v != (cur[idx] ? 1 : 0)) *changed = 1;
+    next[idx] = v;
+}
+
+template <int KW>
+static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, int w, int h) {
+    LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8,
+           hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(1), dim3(64), 0, s, bits, wpr, w, h));
+    return 0;
+}
+
+size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) + 256; }
+
+// bits: denoise_scratch_bytes(w,h) bytes owned by the caller for the duration of the stream work
+int launch_denoise_scratch(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h, int mincnt, int n,
+                           unsigned *bits) {
+    if (n < 0 || mincnt < 0) { set_error("denoise: negative parameter"); return MRCHIP_E_ARG; }
+    if (w <= 2 * n || h <= 2 * n) return 0;      // empty inner rectangle: nothing changes
+    const int wpr = cdiv(w, 32);
+    if (n == 2 && mincnt == 4 && wpr <= 64 * 8) {
+        dim3 grid(cdiv(wpr, 256), h);
+        LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h,
+               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask, pitch, w, h, bits, wpr));
+        if (wpr <= 64) TRY(launch_seq<1>(ctx, s, bits, wpr, w, h));
+        else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, w, h));
+        else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, w, h));
+        else TRY(launch_seq<8>(ctx, s, bits, wpr, w, h));
+        LAUNCH(ctx, s, "denoise_unpack", 1.0 * w * h,
+               hipLaunchKernelGGL(unpack_bits_kernel, grid, dim3(256), 0, s, bits, wpr, mask, pitch, w, h));
+        return 0;
+    }
+    // general path
+    DevBuf a, b, flag;
+    const size_t bytes = (size_t)pitch * h;
+    TRY(a.alloc(ctx, bytes));
+    TRY(b.alloc(ctx, bytes));
+    TRY(flag.alloc(ctx, sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(a.p, mask, bytes, hipMemcpyDeviceToDevice, s));
+    uint8_t *cur = a.as<uint8_t>(), *nxt = b.as<uint8_t>();
+    dim3 grid(cdiv(w, 256), h);
+    for (long long it = 0; it < (long long)w * h + 2; it++) {
+        HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+        LAUNCH(ctx, s, "denoise_jacobi", 2.0 * w * h,
+               hipLaunchKernelGGL(denoise_jacobi_kernel, grid, dim3(256), 0, s, mask, cur, nxt, pitch, w, h, mincnt, n,
+                                  flag.as<int>()));
+        uint8_t *t = cur; cur = nxt; nxt = t;
+        int changed = 0;
+        HIP_TRY(hipMemcpyAsync(&changed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!changed) break;
+    }
+    HIP_TRY(hipMemcpy2DAsync(mask, pitch, cur, pitch, w, h, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // namespace mrchip

@@ -1,0 +1,207 @@
+// PIL Image.thumbnail((int(w/f), int(h/f))) (reference: mrc.py:422-428, 456-462; Pillow
+// Image.thumbnail -> Image.reduce (Reduce.c box mean) -> Image.resize BICUBIC (Resample.c,
+// 8 bpc fixed point, PRECISION_BITS 22, horizontal pass then vertical pass); SURVEY.md 8a
+// row a11).  The size rule and the coefficient tables are host logic (double precision,
+// exactly as Pillow computes them); the pixel passes are integer HIP kernels.
+// Algorithmic bytes: C*P*(1 + 1/f^2) per layer.
+#include <cmath>
+
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+// ---- host logic ----------------------------------------------------------------
+static int round_aspect_w(double number, double aspect, int y) {
+    double fl = floor(number), ce = ceil(number);
+    double kf = fabs(aspect - fl / y), kc = fabs(aspect - ce / y);
+    double pick = (kc < kf) ? ce : fl;          // min() keeps the first on ties
+    return pick < 1 ? 1 : (int)pick;
+}
+static int round_aspect_h(double number, double aspect, int x) {
+    double fl = floor(number), ce = ceil(number);
+    double kf = fl == 0 ? 0 : fabs(aspect - x / fl), kc = ce == 0 ? 0 : fabs(aspect - x / ce);
+    double pick = (kc < kf) ? ce : fl;
+    return pick < 1 ? 1 : (int)pick;
+}
+
+int thumbnail_size(int w, int h, int req_w, int req_h, int *ow, int *oh) {
+    int x = req_w, y = req_h;
+    if (x >= w && y >= h) { *ow = w; *oh = h; return 0; }
+    double aspect = (double)w / (double)h;
+    if ((double)x / (double)y >= aspect) x = round_aspect_w(y * aspect, aspect, y);
+    else y = round_aspect_h(x / aspect, aspect, x);
+    *ow = x; *oh = y;
+    return (x != w || y != h) ? 1 : 0;
+}
+
+static double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Resample.c precompute_coeffs + normalize_coeffs_8bpc; box edges are float32 like Pillow's
+int bicubic_coeffs(int in_size, float in0, float in1, int out_size, std::vector<int32_t> &bounds,
+                   std::vector<int32_t> &kk) {
+    double scale = (double)(in1 - in0) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    double support = 2.0 * filterscale;
+    int ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; xx++) {
+        double center = in0 + (xx + 0.5) * scale;
+        double ww = 0.0, ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        int x;
+        for (x = 0; x < xmax; x++) {
+            double wv = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = wv; ww += wv;
+        }
+        for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; x++) k[x] = 0;
+        for (x = 0; x < ksize; x++) {
+            double v = k[x] * (double)(1 << 22);
+            kk[(size_t)xx * ksize + x] = v < 0 ? (int32_t)(-0.5 + v) : (int32_t)(0.5 + v);
+        }
+        bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+    }
+    return ksize;
+}
+
+// ---- kernels ---------------------------------------------------------------------
+__device__ __forceinline__ unsigned reduce_multiplier(int cells) {
+    // Reduce.c division_UINT32(cells, 8): (UINT32)(2^32 / (256*cells)) evaluated in float32
+    unsigned max_dividend = 256u * (unsigned)cells;
+    float max_int = (float)(1 << 30) * 4.0f;
+    return (unsigned)__fdiv_rn(max_int, (float)max_dividend);
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const uint8_t *src, int spitch, int w, int h, int c, int fx, int fy,
+                                                     uint8_t *dst, int dpitch, int ow, int oh) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= ow) return;
+    const int y0 = oy * fy, y1 = min(h, y0 + fy), x0 = ox * fx, x1 = min(w, x0 + fx);
+    const int cells = (y1 - y0) * (x1 - x0);
+    const unsigned mult = reduce_multiplier(cells), amend = (unsigned)cells / 2;
+    for (int ch = 0; ch < c; ch++) {
+        unsigned ss = 0;
+        for (int yy = y0; yy < y1; yy++)
+            for (int xx = x0; xx < x1; xx++) ss += src[(size_t)yy * spitch + (size_t)xx * c + ch];
+        dst[(size_t)oy * dpitch + (size_t)ox * c + ch] = (uint8_t)(((ss + amend) * mult) >> 24);
+    }
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= 22;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int spitch, int h, uint8_t *dst, int dpitch,
+                                                       int ow, const int32_t *bounds, const int32_t *kk, int ksize) {
+    const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xx >= ow) return;
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int32_t *k = kk + (size_t)xx * ksize;
+    const uint8_t *row = src + (size_t)y * spitch + (size_t)xmin * C;
+    int ss[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) ss[ch] = 1 << 21;
+    for (int x = 0; x < n; x++) {
+        const int kv = k[x];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) ss[ch] += (int)row[x * C + ch] * kv;
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) dst[(size_t)y * dpitch + (size_t)xx * C + ch] = clip8(ss[ch]);
+}
+
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *src, int spitch, int row_bytes, uint8_t *dst,
+                                                       int dpitch, int oh, const int32_t *bounds, const int32_t *kk,
+                                                       int ksize) {
+    const int j = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    if (j >= row_bytes) return;
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int32_t *k = kk + (size_t)yy * ksize;
+    int ss = 1 << 21;
+    for (int y = 0; y < n; y++) ss += (int)src[(size_t)(ymin + y) * spitch + j] * k[y];
+    dst[(size_t)yy * dpitch + j] = clip8(ss);
+}
+
+// Plan of one thumbnail: host tables + scratch sizes.  Built once per (shape, request).
+int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
+    p = ThumbPlan();
+    p.w = w; p.h = h; p.c = c;
+    p.changed = thumbnail_size(w, h, req_w, req_h, &p.ow, &p.oh);
+    if (!p.changed) return 0;
+    // Image.resize: factor = int(extent / size / reducing_gap) or 1   (reducing_gap = 2.0)
+    p.fx = (int)((double)w / p.ow / 2.0); if (p.fx < 1) p.fx = 1;
+    p.fy = (int)((double)h / p.oh / 2.0); if (p.fy < 1) p.fy = 1;
+    float bw = (float)w, bh = (float)h;
+    p.rw = w; p.rh = h;
+    if (p.fx > 1 || p.fy > 1) {
+        p.rw = (w + p.fx - 1) / p.fx; p.rh = (h + p.fy - 1) / p.fy;
+        bw = (float)((double)w / p.fx); bh = (float)((double)h / p.fy);
+    }
+    p.need_h = (p.ow != p.rw) || (bw != (float)p.ow);
+    p.need_v = (p.oh != p.rh) || (bh != (float)p.oh);
+    if (p.need_h) p.ksh = bicubic_coeffs(p.rw, 0.f, bw, p.ow, p.bh_, p.kh_);
+    if (p.need_v) p.ksv = bicubic_coeffs(p.rh, 0.f, bh, p.oh, p.bv_, p.kv_);
+    return 0;
+}
+
+size_t ThumbPlan_table_bytes(const ThumbPlan &p) {
+    return (p.bh_.size() + p.kh_.size() + p.bv_.size() + p.kv_.size()) * sizeof(int32_t) + 64;
+}
+
+// d_tables: device copy of [bh_, kh_, bv_, kv_] in that order (int32), made by the caller.
+// scratch1: rw*rh*c (reduce output, if any); scratch2: ow*rh*c (horizontal pass output)
+int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, const uint8_t *src, int spitch,
+                          uint8_t *dst, int dpitch, const int32_t *d_tables, uint8_t *scratch1, uint8_t *scratch2) {
+    const int c = p.c;
+    if (!p.changed) {
+        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, (size_t)p.w * c, p.h, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    const double alg = (double)c * p.w * p.h + (double)c * p.ow * p.oh;
+    const uint8_t *cur = src;
+    int cpitch = spitch, cw = p.w, ch_ = p.h;
+    if (p.fx > 1 || p.fy > 1) {
+        LAUNCH(ctx, s, "thumb_reduce", alg,
+               hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(p.rw, 256), p.rh), dim3(256), 0, s, cur, cpitch, cw, ch_, c,
+                                  p.fx, p.fy, scratch1, p.rw * c, p.rw, p.rh));
+        cur = scratch1; cpitch = p.rw * c; cw = p.rw; ch_ = p.rh;
+    }
+    const int32_t *d_bh = d_tables, *d_kh = d_bh + p.bh_.size(), *d_bv = d_kh + p.kh_.size(), *d_kv = d_bv + p.bv_.size();
+    if (p.need_h) {
+        uint8_t *o = p.need_v ? scratch2 : dst;
+        int opitch = p.need_v ? p.ow * c : dpitch;
+        if (c == 3)
+            LAUNCH(ctx, s, "thumb_resize_h", p.fx > 1 || p.fy > 1 ? 0.0 : alg,
+                   hipLaunchKernelGGL(resize_h_kernel<3>, dim3(cdiv(p.ow, 256), ch_), dim3(256), 0, s, cur, cpitch, ch_, o,
+                                      opitch, p.ow, d_bh, d_kh, p.ksh));
+        else
+            LAUNCH(ctx, s, "thumb_resize_h", p.fx > 1 || p.fy > 1 ? 0.0 : alg,
+                   hipLaunchKernelGGL(resize_h_kernel<1>, dim3(cdiv(p.ow, 256), ch_), dim3(256), 0, s, cur, cpitch, ch_, o,
+                                      opitch, p.ow, d_bh, d_kh, p.ksh));
+        cur = o; cpitch = opitch; cw = p.ow;
+    }
+    if (p.need_v) {
+        LAUNCH(ctx, s, "thumb_resize_v", 0.0,
+               hipLaunchKernelGGL(resize_v_kernel, dim3(cdiv(cw * c, 256), p.oh), dim3(256), 0, s, cur, cpitch, cw * c, dst,
+                                  dpitch, p.oh, d_bv, d_kv, p.ksv));
+    } else if (cur != dst) {
+        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, cur, cpitch, (size_t)cw * c, ch_, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+}  // namespace mrchip

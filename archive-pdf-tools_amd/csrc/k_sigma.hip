@@ -1,0 +1,212 @@
+// Noise estimate (reference: mrc.py:52-55, 273-296 -> skimage.restoration.estimate_sigma
+// -> pywt.dwtn(x, 'db2')['dd'] -> median(|dd[dd != 0]|) / ppf(0.75)).
+//
+// dwt_dd: one lane per detail coefficient.  The db2 high-pass analysis filter is
+// applied along axis 0 and then axis 1 with PyWavelets' 'symmetric' extension and
+// its exact accumulation order (sum starts at 0, products added one by one, no FMA;
+// for outputs that overhang the right border the mirrored products come first with
+// the filter index descending).  uint8 input is the float32 path (grayimgf,
+// mrc.py:372); bool input is PyWavelets' float64 path (mrc.py:253-254).
+//
+// median: exact order statistics by MSB-first radix select on the IEEE bit patterns
+// of |dd| (non-negative floats order like unsigned integers): 11-bit digit
+// histograms in LDS flushed to global, one tiny scan kernel per digit.  Both middle
+// ranks are tracked so that an even count averages the two middle values in the
+// array's precision, as numpy.median does.
+//
+// Algorithmic bytes: 0.25*P for the page-level estimate (central half crop read once).
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+template <class T>
+struct Db2 { T f[4]; };
+
+// y[o] for i = 2*o + 1 over a length-N signal read through get(idx), idx in [0, N)
+template <class T, class Get>
+__device__ __forceinline__ T dwt_point(const Db2<T> &F, int N, int i, Get get) {
+    constexpr int FL = 4;
+    T sum = 0;
+    int j = 0;
+    if (i >= N) {
+        // right extension first: x[N+t] = x[N-1-t]; filter index i-N-j descending
+        while (i - j >= N) {
+            int kk;
+            for (kk = 0; kk < N && i - j >= N; j++, kk++) sum = add_rn(sum, mul_rn(F.f[i - N - j], get(N - 1 - kk)));
+            for (kk = 0; kk < N && i - j >= N; j++, kk++) sum = add_rn(sum, mul_rn(F.f[i - N - j], get(kk)));
+        }
+    }
+    for (; j <= i && j < FL; j++) sum = add_rn(sum, mul_rn(F.f[j], get(i - j)));
+    while (j < FL) {   // left extension: x[-1-t] = x[t]
+        int kk;
+        for (kk = 0; kk < N && j < FL; j++, kk++) sum = add_rn(sum, mul_rn(F.f[j], get(kk)));
+        for (kk = 0; kk < N && j < FL; j++, kk++) sum = add_rn(sum, mul_rn(F.f[j], get(N - 1 - kk)));
+    }
+    return sum;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dwt_dd_kernel(const uint8_t *src, int pitch, int w, int h, int as_bool,
+                                                     Db2<T> F, T *dd, int w2, int h2) {
+    const int m = blockIdx.x * 256 + threadIdx.x;   // column of dd
+    const int k = blockIdx.y;                       // row of dd
+    if (m >= w2) return;
+    auto px = [&](int yy, int xx) -> T {
+        unsigned v = src[(size_t)yy * pitch + xx];
+        return as_bool ? (T)(v ? 1 : 0) : (T)v;
+    };
+    // axis 0 first (value t[k][xx]), then axis 1
+    auto tcol = [&](int xx) -> T {
+        return dwt_point<T>(F, h, 2 * k + 1, [&](int yy) { return px(yy, xx); });
+    };
+    T v = dwt_point<T>(F, w, 2 * m + 1, tcol);
+    dd[(size_t)k * w2 + m] = v;
+}
+
+template <class T> struct Key;
+template <> struct Key<float> {
+    using U = unsigned;
+    static constexpr int BITS = 32;
+    __device__ static U of(float v) { return __float_as_uint(fabsf(v)); }
+    __device__ static float val(U k) { return __uint_as_float(k); }
+};
+template <> struct Key<double> {
+    using U = unsigned long long;
+    static constexpr int BITS = 64;
+    __device__ static U of(double v) { return (U)__double_as_longlong(fabs(v)); }
+    __device__ static double val(U k) { return __longlong_as_double((long long)k); }
+};
+
+constexpr int DIG = 11;
+constexpr int NBIN = 1 << DIG;
+
+struct SelState {
+    unsigned long long prefix[2];
+    unsigned long long rank[2];
+    unsigned long long count;
+    unsigned hist[2][NBIN];
+    double sigma;
+};
+
+// histogram of the digit at `shift` (width `bits`) among the non-zero |dd| whose higher
+// bits equal prefix[r]
+template <class T>
+__global__ __launch_bounds__(256) void sel_hist_kernel(const T *dd, size_t n, SelState *st, int shift, int bits,
+                                                       int first) {
+    using U = typename Key<T>::U;
+    __shared__ unsigned lh[2][NBIN];
+    for (int i = threadIdx.x; i < 2 * NBIN; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const U p0 = (U)st->prefix[0], p1 = (U)st->prefix[1];
+    const unsigned mask = (1u << bits) - 1u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        T v = dd[i];
+        if (v == (T)0) continue;
+        U key = Key<T>::of(v);
+        unsigned d = (unsigned)(key >> shift) & mask;
+        U hi = (shift + bits >= Key<T>::BITS) ? (U)0 : (key >> (shift + bits));
+        if (first || hi == p0) atomicAdd(&lh[0][d], 1u);
+        if (first || hi == p1) atomicAdd(&lh[1][d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NBIN; i += 256) {
+        unsigned c = (&lh[0][0])[i];
+        if (c) atomicAdd(&(&st->hist[0][0])[i], c);
+    }
+}
+
+// one wave: locate the bins of both ranks, extend the prefixes, clear the histograms;
+// on the last digit produce sigma
+template <class T>
+__global__ __launch_bounds__(64) void sel_scan_kernel(SelState *st, int bits, int first, int last) {
+    using U = typename Key<T>::U;
+    if (threadIdx.x != 0) return;
+    const int nb = 1 << bits;
+    if (first) {
+        unsigned long long m = 0;
+        for (int b = 0; b < nb; b++) m += st->hist[0][b];
+        st->count = m;
+        st->prefix[0] = st->prefix[1] = 0;
+        if (m == 0) { st->rank[0] = st->rank[1] = 0; }
+        else if (m & 1) { st->rank[0] = st->rank[1] = m / 2; }
+        else { st->rank[0] = m / 2 - 1; st->rank[1] = m / 2; }
+    }
+    if (st->count) {
+        for (int r = 0; r < 2; r++) {
+            unsigned long long cum = 0, rank = st->rank[r];
+            int b = 0;
+            for (; b < nb; b++) {
+                unsigned c = st->hist[r][b];
+                if (rank < cum + c) break;
+                cum += c;
+            }
+            st->rank[r] = rank - cum;
+            st->prefix[r] = (st->prefix[r] << bits) | (unsigned long long)b;
+        }
+    }
+    for (int i = 0; i < 2 * NBIN; i++) (&st->hist[0][0])[i] = 0;
+    if (last) {
+        if (st->count == 0) {
+            st->sigma = __longlong_as_double(0x7ff8000000000000LL);       // NaN: median of nothing
+        } else {
+            T a = Key<T>::val((U)st->prefix[0]), b = Key<T>::val((U)st->prefix[1]);
+            T med = (st->count & 1) ? a : (T)(add_rn(a, b) / (T)2);        // numpy: mean of the two middle values
+            st->sigma = (double)med / 0.6744897501960817;                 // scipy.stats.norm.ppf(0.75)
+        }
+    }
+}
+
+template <class T>
+static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h, int as_bool,
+                     T *dd, SelState *st, double alg) {
+    static const double HI[4] = {-0.48296291314453416, 0.8365163037378079, -0.2241438680420134,
+                                 -0.12940952255126037};
+    Db2<T> F;
+    for (int i = 0; i < 4; i++) F.f[i] = (T)HI[i];
+    const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(SelState), s));
+    LAUNCH(ctx, s, sizeof(T) == 4 ? "dwt_dd_f32" : "dwt_dd_f64", alg,
+           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(w2, 256), h2), dim3(256), 0, s, src, pitch, w, h, as_bool,
+                              F, dd, w2, h2));
+    const size_t n = (size_t)w2 * h2;
+    const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+    int shift = Key<T>::BITS;
+    int first = 1;
+    while (shift > 0) {
+        int bits = shift >= DIG ? DIG : shift;
+        if (shift % DIG != 0 && shift == Key<T>::BITS) bits = DIG;      // top digit is a full one
+        shift -= bits;
+        const int last = shift == 0;
+        LAUNCH(ctx, s, "median_hist", 0.0,
+               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks), dim3(256), 0, s, dd, n, st, shift, bits, first));
+        LAUNCH(ctx, s, "median_scan", 0.0,
+               hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(1), dim3(64), 0, s, st, bits, first, last));
+        first = 0;
+    }
+    return 0;
+}
+
+size_t sigma_scratch_bytes(int w, int h, int kind) {
+    const size_t n = (size_t)((w + 3) / 2) * ((h + 3) / 2);
+    return sizeof(SelState) + 256 + n * (kind ? sizeof(double) : sizeof(float));
+}
+
+// scratch: sigma_scratch_bytes(w,h,kind) bytes, 256-byte aligned.  The result lands in
+// *d_sigma (device memory) when the stream reaches it.
+int launch_estimate_sigma_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h,
+                                  int kind, double *d_sigma, void *scratch) {
+    if (w <= 0 || h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
+    SelState *st = reinterpret_cast<SelState *>(scratch);
+    char *ddp = reinterpret_cast<char *>(scratch) + ((sizeof(SelState) + 255) & ~(size_t)255);
+    if (kind == 0) TRY(run_sigma<float>(ctx, s, src, pitch, w, h, 0, reinterpret_cast<float *>(ddp), st, 1.0 * w * h));
+    else TRY(run_sigma<double>(ctx, s, src, pitch, w, h, 1, reinterpret_cast<double *>(ddp), st, 1.0 * w * h));
+    HIP_TRY(hipMemcpyAsync(d_sigma, &st->sigma, sizeof(double), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // namespace mrchip

@@ -161,24 +161,11 @@ int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int n
 int launch_luma601(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int rgb_pitch,
                    uint8_t *gray, int gray_pitch, int w, int h);
 
-// estimate_sigma of a crop; kind 0: u8 values as float32, kind 1: bool as float64.
-// Result (double) is written to *d_sigma (device) -- asynchronous.
-int launch_estimate_sigma(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch,
-                          int w, int h, int kind, double *d_sigma);
-
-int launch_gaussian_u8(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch,
-                       uint8_t *dst, int dpitch, int w, int h, const double *h_weights, int radius);
-
-int launch_denoise(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h,
-                   int mincnt, int n);
 
 int launch_optimise(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int mpitch,
                     const uint8_t *img, int ipitch, uint8_t *out, int opitch,
                     int w, int h, int c, int n, int invert_mask);
 
-// thumbnail on device images; out is tight-pitched [oh][ow*c] with pitch opitch
-int launch_thumbnail(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch, int w, int h,
-                     int c, int ow, int oh, uint8_t *dst, int dpitch);
 
 // hOCR: commit chosen thresholds into the mask in list order
 struct HocrBox {
@@ -189,7 +176,30 @@ struct HocrBox {
     int pitch;
 };
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int mpitch,
-                       const HocrBox *boxes, int nb);
+                       const HocrBox *d_boxes, int nb, int maxw, int maxh, double area);
+
+// thumbnail plan: host-side size rule + fixed-point coefficient tables
+struct ThumbPlan {
+    int w = 0, h = 0, c = 1;
+    int changed = 0;          // 0: image left untouched
+    int ow = 0, oh = 0;       // output size
+    int fx = 1, fy = 1;       // Image.reduce factors
+    int rw = 0, rh = 0;       // size after reduce
+    int need_h = 0, need_v = 0, ksh = 0, ksv = 0;
+    std::vector<int32_t> bh_, kh_, bv_, kv_;
+};
+int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h);
+size_t ThumbPlan_table_bytes(const ThumbPlan &p);
+int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, const uint8_t *src, int spitch,
+                          uint8_t *dst, int dpitch, const int32_t *d_tables, uint8_t *scratch1, uint8_t *scratch2);
+size_t sigma_scratch_bytes(int w, int h, int kind);
+int launch_estimate_sigma_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h,
+                                  int kind, double *d_sigma, void *scratch);
+int launch_gaussian_u8_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch, uint8_t *dst, int dpitch,
+                               int w, int h, const double *h_weights, int radius, float *tmp, int tpitch);
+int launch_denoise_scratch(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h, int mincnt, int n,
+                           unsigned *bits);
+size_t denoise_scratch_bytes(int w, int h);
 
 // host logic
 int thumbnail_size(int w, int h, int req_w, int req_h, int *ow, int *oh);

@@ -1,0 +1,212 @@
+"""GPU parity (through the C ABI) for denoise, optimise, luma, noise estimate, blur,
+thumbnail and the hOCR-box mask: vs the reference goldens and vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mrc_oracle as O
+from mrchip import _lib, mrc, optimiser, synth
+from helpers import kernel_cases, thirdparty_cases, load_npz, load_digests, unpack, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def lib_ctx():
+    return _lib.load(), _lib.default_context()
+
+
+# ---- fast_mask_denoise -------------------------------------------------------------
+def test_denoise_golden():
+    z, cases = kernel_cases('denoise')
+    for _, i, h, w, mincnt, n, _u in cases:
+        m = unpack(z['dn_in_%d' % i], w)
+        r = optimiser.fast_mask_denoise(m, w, h, mincnt, n)
+        assert r is m
+        exp = unpack(z['dn_out_%d' % i], w)
+        assert np.array_equal(m, exp), (i, h, w, mincnt, n, int((m != exp).sum()))
+
+
+@pytest.mark.parametrize('h,w,dens', [(200, 300, 0.1), (333, 2049, 0.3), (64, 4100, 0.5), (1000, 77, 0.05),
+                                      (5, 5, 0.9), (6, 40, 0.7), (300, 8200, 0.2), (17, 33, 1.0)])
+def test_denoise_random_vs_oracle(h, w, dens):
+    rng = np.random.RandomState(h + w)
+    m = rng.rand(h, w) < dens
+    exp = m.copy()
+    O.fast_mask_denoise(exp, w, h, 4, 2)
+    optimiser.fast_mask_denoise(m, w, h, 4, 2)
+    assert np.array_equal(m, exp), int((m != exp).sum())
+
+
+def test_denoise_cascades_and_kat3():
+    # 1-px rules: the removal cascades along the whole row / column (worst case for a parallel sweep)
+    m = np.zeros((300, 4000), dtype=bool)
+    m[10, 3:3990] = True
+    m[50:290, 100] = True
+    m[100:103, 200:3000] = True
+    exp = m.copy()
+    O.fast_mask_denoise(exp, 4000, 300, 4, 2)
+    optimiser.fast_mask_denoise(m, 4000, 300, 4, 2)
+    assert np.array_equal(m, exp)
+    d = load_digests()
+    pat = synth.kat_pattern(1200, 1600)
+    m0 = O.threshold_image(pat, 124)
+    yy, xx = np.mgrid[0:1600, 0:1200].astype(np.int64)
+    for M in (97, 13, 5):
+        m = m0 | (((7919 * xx + 104729 * yy + 31 * xx * yy) % M) == 0)
+        optimiser.fast_mask_denoise(m, 1200, 1600, 4, 2)
+        assert sha(m) == d['kat3'][str(M)]['out']
+
+
+def test_denoise_general_parameters():
+    rng = np.random.RandomState(5)
+    for (mincnt, n) in [(2, 1), (6, 3), (0, 2), (30, 2), (3, 0)]:
+        m = rng.rand(90, 110) < 0.35
+        exp = m.copy()
+        O.fast_mask_denoise(exp, 110, 90, mincnt, n)
+        optimiser.fast_mask_denoise(m, 110, 90, mincnt, n)
+        assert np.array_equal(m, exp), (mincnt, n)
+
+
+# ---- optimise ------------------------------------------------------------------------
+def test_optimise_golden():
+    z, cases = kernel_cases('optimise')
+    for _, i, h, w, n, _a, _b in cases:
+        m = unpack(z['opt_mask_%d' % i], w)
+        g, c = z['opt_g_%d' % i], z['opt_c_%d' % i]
+        got = optimiser.optimise_gray2(m, g, w, h, n)
+        assert np.array_equal(got, z['opt_g2_%d' % i]), ('gray', i, int((got != z['opt_g2_%d' % i]).sum()))
+        got = optimiser.optimise_rgb2(m, c, w, h, n)
+        assert np.array_equal(got, z['opt_c2_%d' % i]), ('rgb', i, int((got != z['opt_c2_%d' % i]).sum()))
+
+
+@pytest.mark.parametrize('h,w,dens,n', [(120, 700, 0.1, 3), (120, 700, 0.1, 10), (300, 4111, 0.08, 10),
+                                        (64, 4096, 0.5, 3), (500, 17, 0.2, 10), (40, 8200, 0.1, 10),
+                                        (33, 100, 0.0, 3), (33, 100, 1.0, 10), (50, 60, 0.3, 1), (50, 60, 0.3, 0)])
+def test_optimise_random_vs_oracle(h, w, dens, n):
+    rng = np.random.RandomState(h * 31 + w + n)
+    m = rng.rand(h, w) < dens
+    g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    c = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    assert np.array_equal(optimiser.optimise_gray2(m, g, w, h, n), O.optimise_gray2(m, g, w, h, n))
+    assert np.array_equal(optimiser.optimise_rgb2(m, c, w, h, n), O.optimise_rgb2(m, c, w, h, n))
+    lib, ctx = lib_ctx()
+    out = np.empty_like(c)
+    _lib.check(lib.mrchip_optimise(ctx.handle, _lib.ptr(m.view(np.uint8)), _lib.ptr(c), _lib.ptr(out), w, h, 3, n, 1))
+    assert np.array_equal(out, O.optimise_rgb2(~m, c, w, h, n))          # fused mask inversion (mrc.py:439)
+
+
+def test_optimise_kat4():
+    d = load_digests()
+    pat, pat3 = synth.kat_pattern(1200, 1600), synth.kat_pattern(1200, 1600, 3)
+    m0 = O.threshold_image(pat, 124)
+    assert sha(optimiser.optimise_rgb2(m0, pat3, 1200, 1600, 3)) == d['kat4a']
+    assert sha(optimiser.optimise_rgb2(~m0, pat3, 1200, 1600, 10)) == d['kat4b']
+    assert sha(optimiser.optimise_gray2(m0, pat, 1200, 1600, 3)) == d['kat4c']
+
+
+# ---- luma / sigma / gaussian / thumbnail ------------------------------------------------
+def test_luma_golden_and_random():
+    z, _ = load_npz('thirdparty.npz')
+    lib, ctx = lib_ctx()
+    for rgb in (z['luma_in'], np.random.RandomState(1).randint(0, 256, (301, 1003, 3)).astype(np.uint8)):
+        h, w = rgb.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        _lib.check(lib.mrchip_luma601(ctx.handle, _lib.ptr(np.ascontiguousarray(rgb)), _lib.ptr(out), w, h))
+        assert np.array_equal(out, O.luma601(rgb))
+    out = np.empty(z['luma_out'].shape, np.uint8)
+    _lib.check(lib.mrchip_luma601(ctx.handle, _lib.ptr(np.ascontiguousarray(z['luma_in'])), _lib.ptr(out),
+                                  out.shape[1], out.shape[0]))
+    assert np.array_equal(out, z['luma_out'])
+
+
+def test_sigma_golden_and_random():
+    z, cases = thirdparty_cases('sigma')
+    for _, i, h, w in cases:
+        f = z['sig_f_%d' % i]
+        b = unpack(z['sig_b_%d' % i], w)
+        vals = z['sig_vals_%d' % i]
+        assert mrc.mean_estimate_sigma(f.astype(np.float32)) == vals[0], i
+        assert mrc.mean_estimate_sigma(b) == vals[1], i
+        assert mrc.estimate_noise(f.astype(np.float32)) == vals[2], i
+    rng = np.random.RandomState(3)
+    for (h, w) in [(1500, 2000), (751, 1001), (4, 4), (3, 50), (50, 3), (2, 2), (1, 9)]:
+        f = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        assert mrc.mean_estimate_sigma(f) == O.estimate_sigma(f.astype(np.float32)), (h, w)
+        b = rng.rand(h, w) < 0.15
+        got, exp = mrc.mean_estimate_sigma(b), O.estimate_sigma(b)
+        assert got == exp or (np.isnan(got) and np.isnan(exp)), (h, w, got, exp)
+    z0 = np.zeros((40, 40), np.uint8)
+    assert np.isnan(mrc.estimate_noise(z0))                  # all-zero detail band -> NaN (no blur)
+    p = synth.kat_pattern(800, 600, 3)
+    assert mrc.estimate_noise(O.luma601(p)) == 15.725569182346643
+
+
+def test_gaussian_golden_and_random():
+    z, cases = thirdparty_cases('gauss')
+    lib, ctx = lib_ctx()
+    for _, i, h, w, sig in cases:
+        g = np.ascontiguousarray(z['gau_in_%d' % i])
+        wts = np.ascontiguousarray(z['gau_w_%d' % i])
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, float(sig),
+                                          _lib.ptr(wts, _lib.f64p), (len(wts) - 1) // 2))
+        assert np.array_equal(out, z['gau_out_%d' % i].astype(np.uint8)), (i, sig)
+    rng = np.random.RandomState(9)
+    for sig, (h, w) in [(0.39, (700, 900)), (0.6, (333, 1001)), (1.3, (50, 2000)), (5.0, (100, 100)), (0.6, (2, 3))]:
+        g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        wts, radius = mrc.gaussian_weights(sig)
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
+        exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
+        assert np.array_equal(out, exp), (sig, h, w)
+        # library-built table (libm exp)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, None, 0))
+        wl, _ = O.gaussian_weights_libm(sig)
+        assert np.array_equal(out, O.gaussian_filter(g.astype(np.float32), sig, weights=wl).astype(np.uint8))
+
+
+def test_thumbnail_golden_and_random():
+    z, cases = thirdparty_cases('thumb')
+    lib, ctx = lib_ctx()
+
+    def run(im, rw, rh):
+        h, w = im.shape[:2]
+        c = 1 if im.ndim == 2 else 3
+        ow, oh = C.c_int(), C.c_int()
+        lib.mrchip_thumbnail_size(w, h, rw, rh, C.byref(ow), C.byref(oh))
+        out = np.empty((oh.value, ow.value) if c == 1 else (oh.value, ow.value, 3), np.uint8)
+        _lib.check(lib.mrchip_thumbnail(ctx.handle, _lib.ptr(np.ascontiguousarray(im)), w, h, c, rw, rh, _lib.ptr(out)))
+        return out
+    for _, i, h, w, f, ch in cases:
+        got = run(z['thb_in_%d' % i], int(w / f), int(h / f))
+        exp = z['thb_out_%d' % i]
+        assert got.shape == exp.shape and np.array_equal(got, exp), (i, h, w, f, ch)
+    rng = np.random.RandomState(11)
+    for (h, w, f, c) in [(3000, 4000, 3, 3), (1500, 2000, 4, 3), (999, 1333, 3, 1), (600, 801, 5, 3), (700, 500, 7, 1)]:
+        im = rng.randint(0, 256, (h, w) if c == 1 else (h, w, 3)).astype(np.uint8)
+        got = run(im, int(w / f), int(h / f))
+        exp = O.thumbnail(im, int(w / f), int(h / f))
+        assert got.shape == exp.shape and np.array_equal(got, exp), (h, w, f, c)
+
+
+# ---- hOCR box mask ------------------------------------------------------------------------
+def test_hocr_mask_vs_oracle():
+    for seed, ns, dpi in [(0, 6.0, None), (1, 2.0, 150), (2, 12.0, None), (3, 0.0, 300)]:
+        img, hocr = synth.synth_page(900, 700, 1, seed=seed, noise_sigma=ns, line_div=24)
+        boxes = O.hocr_boxes(hocr, 900, 700)
+        assert len(boxes) >= 5
+        exp = np.zeros((700, 900), dtype=bool)
+        dec = []
+        O.create_hocr_mask(img, exp, boxes, dpi, dec)
+        got = np.zeros((700, 900), dtype=bool)
+        mrc.create_hocr_mask(img, got, hocr, dpi=dpi)
+        assert np.array_equal(got, exp), (seed, int((got != exp).sum()), dec)
+        # decisions through the C ABI
+        lib, ctx = lib_ctx()
+        d = np.zeros(len(boxes), np.int32)
+        m2 = np.zeros((700, 900), np.uint8)
+        _lib.check(lib.mrchip_hocr_mask(ctx.handle, _lib.ptr(img), _lib.ptr(m2), 900, 700, _lib.ptr(boxes, _lib.i32p),
+                                        len(boxes), O.window_size(dpi), _lib.ptr(d, _lib.i32p)))
+        assert d.tolist() == dec
+    assert {0, 1, 2} <= set(dec) | {0, 1, 2} and len(dec) > 0
