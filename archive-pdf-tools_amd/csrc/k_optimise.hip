@@ -249,7 +249,10 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const uint8_t *__restric
 #pragma unroll
                 for (int c = 0; c < C; c++) reinterpret_cast<uint4 *>(o)[c] = res[c];
             } else {
-                for (int j = 0; j < (w - x0) * C; j++) o[j] = (uint8_t)px_byte<C>(res, j);
+                const int nbytes = (w - x0) * C;
+#pragma unroll
+                for (int j = 0; j < OP * C; j++)
+                    if (j < nbytes) o[j] = (uint8_t)resb[j];
             }
         }
 #pragma unroll

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pages/s of the full MRC decomposition (mask + fg + bg) of
+4000x3000 RGB pages with hOCR boxes, bg downsample 3 -- BASELINE.json configs[1] --
+on N MI355X GPUs of one node, one process per GPU, pages sharded across ranks with no
+data-path collective.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over this rank's batch of --pages pages whose pixels
+are already resident in HBM (outputs stay in HBM; the PCIe-inclusive drop-in rate is
+printed as `pcie_inclusive_pages_per_s`, it is never `value`).  Rank 0 prints ONE JSON line.
+
+roofline: the kernel with the largest share of GPU time, measured with HIP events on the
+stream each launch goes to (mrchip_prof_*), algorithmic bytes per SURVEY.md 8d.
+cpu_baseline: the C restatement of the reference (oracle/, kind "port") timed on this
+host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+W, H, C = 4000, 3000, 3
+BG_DOWNSAMPLE = 3
+DISTINCT = 4                # distinct synthetic pages, cycled through the batch
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_pages(n_distinct, rank):
+    from mrchip import synth, mrc
+    pages = []
+    for i in range(n_distinct):
+        seed = 202 + i + 1000 * rank          # seed 202 is the page the reference digested (digests.json)
+        img, hocr = synth.synth_page(W, H, C, seed=seed, noise_sigma=6.0, line_div=60)
+        boxes = mrc.hocr_boxes(hocr, W, H)
+        pages.append((img, hocr, boxes))
+    return pages
+
+
+def cpu_baseline(sample_pages):
+    """oracle (C port of the reference) on `sample_pages`, single thread."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mrc_oracle as O
+    O.lib()
+    t0 = time.time()
+    n = 0
+    for img, hocr, _ in sample_pages:
+        g = O.create_mrc_hocr_components(img, hocr, dpi=None, bg_downsample=BG_DOWNSAMPLE, denoise_mask='fast')
+        for _ in g:
+            pass
+        n += 1
+        if time.time() - t0 > 25:
+            break
+    dt = time.time() - t0
+    return {'value': round(n / dt, 4), 'unit': 'pages/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d of the same 4000x3000 RGB pages through oracle/mrc_oracle.c (-O3, 1 thread), %.1f s'
+                      % (n, dt), 'host_cpus': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--pages', type=int, default=32, help='pages per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist = dist_
+
+    from mrchip import _lib, mrc
+    ctx = _lib.Context(local_rank if _lib.mrchip_visible_devices() > local_rank else 0)
+    lib = _lib.load()
+    info = ctx.info()
+
+    # work queue: rank 0 decides the page seeds and broadcasts the descriptor table (bytes, not pixels)
+    if dist is not None:
+        import torch
+        desc = torch.zeros(4, dtype=torch.int64, device='cuda')
+        if rank == 0:
+            desc[:] = torch.tensor([W, H, a.pages, DISTINCT])
+        dist.broadcast(desc, 0)
+        assert desc.tolist() == [W, H, a.pages, DISTINCT]
+
+    host_pages = make_pages(DISTINCT, rank)
+    window = 51                                    # dpi=None (bin/compress-pdf-images:66-70)
+    pages = []
+    for i in range(a.pages):
+        img, hocr, boxes = host_pages[i % DISTINCT]
+        pg = mrc._Page(ctx, W, H, C)
+        pg.upload(img)
+        pages.append((pg, boxes))
+    ctx.sync()
+
+    def step():
+        for pg, boxes in pages:
+            pg.mask_begin(boxes, window)
+        for pg, boxes in pages:
+            s = pg.sigma()
+            pg.mask_finish(s, True)
+            pg.layer(0, None)
+            pg.layer(1, BG_DOWNSAMPLE)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.prof_report()
+    ctx.prof_enable(False)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # untimed: parity evidence + PCIe-inclusive drop-in rate on rank 0
+    extra = {}
+    if rank == 0:
+        pg, boxes = pages[0]
+        mask = pg.download_mask()
+        try:
+            with open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')) as f:
+                dg = json.load(f)['c2_dpiNone']
+            extra['parity'] = 'mask sha256 %s the reference digest' % ('==' if sha(mask) == dg['mask'] else '!=')
+        except Exception as e:     # pragma: no cover
+            extra['parity'] = 'unchecked: %s' % e
+        img, hocr, _ = host_pages[0]
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            for _ in mrc.create_mrc_hocr_components(img, hocr, dpi=None, bg_downsample=BG_DOWNSAMPLE,
+                                                    denoise_mask='fast', ctx=ctx):
+                pass
+        extra['pcie_inclusive_pages_per_s'] = round(reps / (time.perf_counter() - t1), 2)
+
+    total_pages = a.pages * a.steps * world
+    value = total_pages / dt
+    # dominant kernel by GPU time
+    dom = max(prof.items(), key=lambda kv: kv[1]['ms']) if prof else None
+    roof = None
+    if dom:
+        name, r = dom
+        ms = r['ms'] / r['launches']
+        achieved = r['alg_bytes'] / r['launches'] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roof = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                'avg_launch_ms': round(ms, 4), 'launches': r['launches'],
+                'alg_bytes_per_launch': r['alg_bytes'] / r['launches']}
+    kernels = {k: {'ms_per_launch': round(v['ms'] / v['launches'], 4), 'launches': v['launches'],
+                   'alg_GBps': round(v['alg_bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in sorted(prof.items())}
+    if rank == 0:
+        cpu = None if a.no_cpu_baseline else cpu_baseline(host_pages)
+        line = {
+            'metric': 'pages/sec MRC decompose (4000x3000 RGB)', 'value': round(value, 2), 'unit': 'pages/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: 4000x3000 RGB page + hOCR line boxes, dpi=None (window 51), '
+                                   'bg_downsample=3, denoise fast, full create_mrc_hocr_components',
+                       'pages_per_gpu_per_step': a.pages, 'distinct_pages': DISTINCT,
+                       'hocr_boxes_per_page': int(len(host_pages[0][2])), 'sharding': 'pages round-robin over ranks'},
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'device': info['name'].strip(),
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    for pg, _ in pages:
+        pg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
