@@ -48,7 +48,9 @@ MRCHIP_EXPORT int mrchip_luma601(mrchip_ctx *ctx, const uint8_t *rgb, uint8_t *g
     TRY(src.alloc(ctx, w, h, 3));
     TRY(dst.alloc(ctx, w, h));
     TRY(upload_2d(s, src.p, src.pitch, rgb, w * 3, w * 3, h));
-    TRY(launch_luma601(ctx, s, src.p, src.pitch, dst.p, dst.pitch, w, h));
+    Plane ps, pd;
+    ps.p = src.p; ps.pitch = src.pitch; pd.p = dst.p; pd.pitch = dst.pitch;
+    TRY(launch_luma601(ctx, s, ps, pd, w, h, 1));
     TRY(download_2d(s, gray, w, dst.p, dst.pitch, w, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -64,7 +66,9 @@ MRCHIP_EXPORT int mrchip_mask_denoise(mrchip_ctx *ctx, uint8_t *mask, int w, int
     TRY(m.alloc(ctx, w, h));
     TRY(bits.alloc(ctx, denoise_scratch_bytes(w, h)));
     TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
-    TRY(launch_denoise_scratch(ctx, s, m.p, m.pitch, w, h, mincnt, n_size, bits.as<unsigned>()));
+    Plane pm;
+    pm.p = m.p; pm.pitch = m.pitch;
+    TRY(launch_denoise_batch(ctx, s, pm, w, h, mincnt, n_size, bits.as<unsigned>(), 0, 1));
     TRY(download_2d(s, mask, w, m.p, m.pitch, w, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -78,12 +82,17 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     if (w == 0 || h == 0) return 0;
     hipStream_t s = ctx->streams[0];
     Img8 m, i, o;
+    DevBuf jb;
     TRY(m.alloc(ctx, w, h));
     TRY(i.alloc(ctx, w, h, channels));
     TRY(o.alloc(ctx, w, h, channels));
+    TRY(jb.alloc(ctx, sizeof(OptJob)));
     TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
     TRY(upload_2d(s, i.p, i.pitch, img, w * channels, w * channels, h));
-    TRY(launch_optimise(ctx, s, m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, channels, n_size, invert_mask));
+    OptJob job = {m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, n_size, invert_mask ? 1 : 0};
+    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
+    TRY(launch_optimise_jobs(ctx, s, jb.as<OptJob>(), 1, w, h, channels, n_size));
     TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -103,7 +112,9 @@ MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int
     TRY(scratch.alloc(ctx, sigma_scratch_bytes(w, h, kind)));
     TRY(res.alloc(ctx, 64));
     TRY(upload_2d(s, m.p, m.pitch, arr, stride, w, h));
-    TRY(launch_estimate_sigma_scratch(ctx, s, m.p, m.pitch, w, h, kind, res.as<double>(), scratch.p));
+    Plane pm;
+    pm.p = m.p; pm.pitch = m.pitch;
+    TRY(launch_estimate_sigma_batch(ctx, s, pm, w, h, kind, res.as<double>(), scratch.p, 0, 1));
     HIP_TRY(hipMemcpyAsync(sigma, res.p, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -138,7 +149,18 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
     TRY(b.alloc(ctx, w, h));
     TRY(tmp.alloc(ctx, (size_t)tp * h * sizeof(float)));
     TRY(upload_2d(s, a.p, a.pitch, gray, w, w, h));
-    TRY(launch_gaussian_u8_scratch(ctx, s, a.p, a.pitch, b.p, b.pitch, w, h, weights, radius, tmp.as<float>(), tp));
+    if (radius < 0 || radius > GMAXR) { set_error("gaussian: radius %d outside [0,%d]", radius, GMAXR); return MRCHIP_E_UNSUPPORTED; }
+    DevBuf gw;
+    TRY(gw.alloc(ctx, sizeof(GaussW)));
+    GaussW G;
+    memset(&G, 0, sizeof(G));
+    G.radius = radius;
+    for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
+    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    Plane pa, pb;
+    pa.p = a.p; pa.pitch = a.pitch; pb.p = b.p; pb.pitch = b.pitch;
+    TRY(launch_gaussian_batch(ctx, s, pa, pb, w, h, gw.as<GaussW>(), tmp.as<float>(), tp, 0, 1));
     TRY(download_2d(s, out, w, b.p, b.pitch, w, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -174,8 +196,12 @@ MRCHIP_EXPORT int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, in
     HIP_TRY(hipMemcpyAsync(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bv_.size();
     HIP_TRY(hipMemcpyAsync(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice, s));
     TRY(upload_2d(s, src.p, src.pitch, in, w * c, w * c, h));
-    TRY(launch_thumbnail_plan(ctx, s, p, src.p, src.pitch, dst.as<uint8_t>(), p.ow * c, tab.as<int32_t>(),
-                              s1.as<uint8_t>(), s2.as<uint8_t>()));
+    Plane psrc, pdst, p1, p2;
+    psrc.p = src.p; psrc.pitch = src.pitch;
+    pdst.p = dst.as<uint8_t>(); pdst.pitch = p.ow * c;
+    p1.p = s1.as<uint8_t>(); p1.pitch = p.rw * c;
+    p2.p = s2.as<uint8_t>(); p2.pitch = p.ow * c;
+    TRY(launch_thumbnail_plan(ctx, s, p, psrc, pdst, tab.as<int32_t>(), p1, p2, 1));
     HIP_TRY(hipMemcpyAsync(out, dst.p, (size_t)p.ow * p.oh * c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -35,11 +35,13 @@ __device__ __forceinline__ unsigned nz_nibble(unsigned d) {
     return (t * 0x01020408u) >> 24 & 0xFu;
 }
 
-__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int pitch, int w, int h,
-                                                        unsigned *bits, int wpr /* words per row */) {
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int pitch, size_t mstride, int w, int h,
+                                                        unsigned *bits, int wpr /* words per row */, size_t bstride) {
     const int y = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= wpr) return;
+    mask += (size_t)blockIdx.z * mstride;
+    bits += (size_t)blockIdx.z * bstride;
     const uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
     unsigned word = 0;
     if (j * 32 + 32 <= w) {
@@ -55,11 +57,13 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int
 
 __device__ __forceinline__ unsigned spread_nibble(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
-__global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned *bits, int wpr, uint8_t *mask, int pitch,
-                                                          int w, int h) {
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned *bits, int wpr, size_t bstride, uint8_t *mask,
+                                                          int pitch, size_t mstride, int w, int h) {
     const int y = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= wpr) return;
+    mask += (size_t)blockIdx.z * mstride;
+    bits += (size_t)blockIdx.z * bstride;
     const unsigned word = bits[(size_t)y * wpr + j];
     uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
     if (j * 32 + 32 <= w) {
@@ -145,9 +149,10 @@ __device__ __forceinline__ Row<KW> load_row(const unsigned *bits, int wpr, int y
 }
 
 template <int KW>
-__global__ __launch_bounds__(64) void denoise_seq_kernel(unsigned *bits, int wpr, int w, int h) {
+__global__ __launch_bounds__(64) void denoise_seq_kernel(unsigned *bits, int wpr, size_t bstride, int w, int h) {
     // in place: row y is overwritten with its final value after rows y+1, y+2 have been read
     const int lane = threadIdx.x;
+    bits += (size_t)blockIdx.x * bstride;      // one wave per page
     constexpr int n = 2;
     if (h <= 2 * n || w <= 2 * n) return;
     // inner-column mask: columns [n, w-n)
@@ -263,45 +268,49 @@ __global__ __launch_bounds__(256) void denoise_jacobi_kernel(const uint8_t *orig
 }
 
 template <int KW>
-static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, int w, int h) {
-    LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8,
-           hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(1), dim3(64), 0, s, bits, wpr, w, h));
+static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, size_t bstride, int w, int h, int npages) {
+    LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8 * npages,
+           hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
     return 0;
 }
 
 size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) + 256; }
 
-// bits: denoise_scratch_bytes(w,h) bytes owned by the caller for the duration of the stream work
-int launch_denoise_scratch(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h, int mincnt, int n,
-                           unsigned *bits) {
+int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
+                         size_t bits_stride, int npages) {
     if (n < 0 || mincnt < 0) { set_error("denoise: negative parameter"); return MRCHIP_E_ARG; }
     if (w <= 2 * n || h <= 2 * n) return 0;      // empty inner rectangle: nothing changes
     const int wpr = cdiv(w, 32);
+    const int pitch = mask.pitch;
     if (n == 2 && mincnt == 4 && wpr <= 64 * 8) {
-        dim3 grid(cdiv(wpr, 256), h);
-        LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h,
-               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask, pitch, w, h, bits, wpr));
-        if (wpr <= 64) TRY(launch_seq<1>(ctx, s, bits, wpr, w, h));
-        else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, w, h));
-        else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, w, h));
-        else TRY(launch_seq<8>(ctx, s, bits, wpr, w, h));
-        LAUNCH(ctx, s, "denoise_unpack", 1.0 * w * h,
-               hipLaunchKernelGGL(unpack_bits_kernel, grid, dim3(256), 0, s, bits, wpr, mask, pitch, w, h));
+        dim3 grid(cdiv(wpr, 256), h, npages);
+        LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h * npages,
+               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask.p, pitch, mask.stride, w, h, bits, wpr,
+                                  bits_stride));
+        if (wpr <= 64) TRY(launch_seq<1>(ctx, s, bits, wpr, bits_stride, w, h, npages));
+        else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, bits_stride, w, h, npages));
+        else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, bits_stride, w, h, npages));
+        else TRY(launch_seq<8>(ctx, s, bits, wpr, bits_stride, w, h, npages));
+        LAUNCH(ctx, s, "denoise_unpack", 1.0 * w * h * npages,
+               hipLaunchKernelGGL(unpack_bits_kernel, grid, dim3(256), 0, s, bits, wpr, bits_stride, mask.p, pitch,
+                                  mask.stride, w, h));
         return 0;
     }
+  for (int pgi = 0; pgi < npages; pgi++) {
+    uint8_t *mask_p = mask.page(pgi);
     // general path
     DevBuf a, b, flag;
     const size_t bytes = (size_t)pitch * h;
     TRY(a.alloc(ctx, bytes));
     TRY(b.alloc(ctx, bytes));
     TRY(flag.alloc(ctx, sizeof(int)));
-    HIP_TRY(hipMemcpyAsync(a.p, mask, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(a.p, mask_p, bytes, hipMemcpyDeviceToDevice, s));
     uint8_t *cur = a.as<uint8_t>(), *nxt = b.as<uint8_t>();
     dim3 grid(cdiv(w, 256), h);
     for (long long it = 0; it < (long long)w * h + 2; it++) {
         HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), s));
         LAUNCH(ctx, s, "denoise_jacobi", 2.0 * w * h,
-               hipLaunchKernelGGL(denoise_jacobi_kernel, grid, dim3(256), 0, s, mask, cur, nxt, pitch, w, h, mincnt, n,
+               hipLaunchKernelGGL(denoise_jacobi_kernel, grid, dim3(256), 0, s, mask_p, cur, nxt, pitch, w, h, mincnt, n,
                                   flag.as<int>()));
         uint8_t *t = cur; cur = nxt; nxt = t;
         int changed = 0;
@@ -309,8 +318,9 @@ int launch_denoise_scratch(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pi
         HIP_TRY(hipStreamSynchronize(s));
         if (!changed) break;
     }
-    HIP_TRY(hipMemcpy2DAsync(mask, pitch, cur, pitch, w, h, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(mask_p, pitch, cur, pitch, w, h, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
+  }
     return 0;
 }
 

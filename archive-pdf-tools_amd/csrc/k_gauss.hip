@@ -13,8 +13,6 @@
 
 namespace mrchip {
 
-constexpr int GMAXR = 60;
-struct GaussW { double w[2 * GMAXR + 1]; int radius; };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     if (i >= 0 && i < n) return i;
@@ -25,10 +23,13 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
-__global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int spitch, float *tmp, int tpitch,
-                                                      int w, int h, GaussW G) {
+__global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int spitch, size_t sstride, float *tmp,
+                                                      int tpitch, size_t tstride, int w, int h, const GaussW *Gs) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    src += (size_t)blockIdx.z * sstride;
+    tmp += (size_t)blockIdx.z * tstride;
+    const GaussW &G = Gs[blockIdx.z];
     const int r = G.radius;
     double acc = __dmul_rn((double)src[(size_t)y * spitch + x], G.w[r]);
     for (int j = -r; j < 0; j++) {
@@ -39,10 +40,13 @@ __global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int sp
     tmp[(size_t)y * tpitch + x] = (float)acc;
 }
 
-__global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpitch, uint8_t *dst, int dpitch,
-                                                      int w, int h, GaussW G) {
+__global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpitch, size_t tstride, uint8_t *dst,
+                                                      int dpitch, size_t dstride, int w, int h, const GaussW *Gs) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    tmp += (size_t)blockIdx.z * tstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const GaussW &G = Gs[blockIdx.z];
     const int r = G.radius;
     const float *row = tmp + (size_t)y * tpitch;
     double acc = __dmul_rn((double)row[x], G.w[r]);
@@ -77,23 +81,17 @@ int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
     return 0;
 }
 
-// tmp: h * tpitch floats of scratch
-int launch_gaussian_u8_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch, uint8_t *dst, int dpitch,
-                               int w, int h, const double *h_weights, int radius, float *tmp, int tpitch) {
-    if (radius < 0 || radius > GMAXR) { set_error("gaussian: radius %d outside [0,%d]", radius, GMAXR); return MRCHIP_E_UNSUPPORTED; }
-    if (radius == 0) {
-        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, w, h, hipMemcpyDeviceToDevice, s));
-        return 0;
-    }
-    GaussW G;
-    memset(&G, 0, sizeof(G));
-    G.radius = radius;
-    for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = h_weights[i];
-    dim3 grid(cdiv(w, 256), h);
-    LAUNCH(ctx, s, "gauss_v", 5.0 * w * h,
-           hipLaunchKernelGGL(gauss_v_kernel, grid, dim3(256), 0, s, src, spitch, tmp, tpitch, w, h, G));
-    LAUNCH(ctx, s, "gauss_h", 5.0 * w * h,
-           hipLaunchKernelGGL(gauss_h_kernel, grid, dim3(256), 0, s, tmp, tpitch, dst, dpitch, w, h, G));
+// radius 0 (weight 1.0) is the identity: float32(u8) -> u8, so pages without blur (sigma_est <= 1,
+// mrc.py:309) ride along in the same launch.
+int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
+                          float *tmp, int tpitch, size_t tstride, int npages) {
+    dim3 grid(cdiv(w, 256), h, npages);
+    LAUNCH(ctx, s, "gauss_v", 5.0 * w * h * npages,
+           hipLaunchKernelGGL(gauss_v_kernel, grid, dim3(256), 0, s, src.p, src.pitch, src.stride, tmp, tpitch, tstride, w, h,
+                              d_weights));
+    LAUNCH(ctx, s, "gauss_h", 5.0 * w * h * npages,
+           hipLaunchKernelGGL(gauss_h_kernel, grid, dim3(256), 0, s, tmp, tpitch, tstride, dst.p, dst.pitch, dst.stride, w, h,
+                              d_weights));
     return 0;
 }
 

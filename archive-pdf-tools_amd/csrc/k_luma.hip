@@ -10,11 +10,13 @@ __device__ __forceinline__ unsigned luma1(unsigned r, unsigned g, unsigned b) {
     return (r * 19595u + g * 38470u + b * 7471u + 0x8000u) >> 16;
 }
 
-__global__ __launch_bounds__(256) void luma601_kernel(const uint8_t *rgb, int rgb_pitch, uint8_t *gray,
-                                                      int gray_pitch, int w, int h) {
+__global__ __launch_bounds__(256) void luma601_kernel(const uint8_t *rgb, int rgb_pitch, size_t rgb_stride,
+                                                      uint8_t *gray, int gray_pitch, size_t gray_stride, int w, int h) {
     const int y = blockIdx.y;
     const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (x4 >= w) return;
+    rgb += (size_t)blockIdx.z * rgb_stride;
+    gray += (size_t)blockIdx.z * gray_stride;
     const uint8_t *row = rgb + (size_t)y * rgb_pitch + (size_t)x4 * 3;
     uint8_t *out = gray + (size_t)y * gray_pitch + x4;
     if (x4 + 4 <= w) {
@@ -30,11 +32,11 @@ __global__ __launch_bounds__(256) void luma601_kernel(const uint8_t *rgb, int rg
     }
 }
 
-int launch_luma601(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int rgb_pitch, uint8_t *gray,
-                   int gray_pitch, int w, int h) {
-    dim3 grid(cdiv(cdiv(w, 4), 256), h);
-    LAUNCH(ctx, s, "luma601", 4.0 * w * h,
-           hipLaunchKernelGGL(luma601_kernel, grid, dim3(256), 0, s, rgb, rgb_pitch, gray, gray_pitch, w, h));
+int launch_luma601(mrchip_ctx *ctx, hipStream_t s, Plane rgb, Plane gray, int w, int h, int npages) {
+    dim3 grid(cdiv(cdiv(w, 4), 256), h, npages);
+    LAUNCH(ctx, s, "luma601", 4.0 * w * h * npages,
+           hipLaunchKernelGGL(luma601_kernel, grid, dim3(256), 0, s, rgb.p, rgb.pitch, rgb.stride, gray.p, gray.pitch,
+                              gray.stride, w, h));
     return 0;
 }
 

@@ -9,134 +9,134 @@
 // The second sum reads OUTPUT rows above the current one (never the current
 // row), so rows are strictly sequential and all pixels of a row are parallel.
 //
-// v1 schedule: one workgroup per page-layer walks the rows; thread t owns the
-// P=16 adjacent columns [16t, 16t+16) and keeps their vertical running sums
-// (FIR: masked image sums + mask count over rows [ys,ye); IIR: output sums over
-// rows [ys,y)) in registers.  Per row the threads publish their column sums
-// (8 x u16 per column, one 16-byte LDS entry) and slide the horizontal windows
-// over the LDS row.  All global loads a row needs are independent of the
-// serial chain and are issued one row ahead.  int32 throughout, truncating
-// division (exact: see div_small).  Batches run one workgroup per page-layer
-// (256 CUs -> 128 pages' fg+bg concurrently).
+// Schedule: one workgroup per page-layer (blockIdx.x = job) walks the rows;
+// thread t owns the P adjacent columns [P*t, P*t+P) and keeps their vertical
+// running sums (FIR: masked image sums + mask count over rows [ys,ye); IIR:
+// output sums over rows [ys,y)) in registers.  Per row the threads publish their
+// column sums to two LDS rows and slide the horizontal windows over them.  The
+// LDS rows carry one pad element per P columns so that the lane-strided accesses
+// of a wave fall on distinct banks.  All global loads a row needs are
+// independent of the serial chain and are issued one row ahead.  int32
+// throughout, truncating division (exact: see div_small).  A batch is one launch:
+// 2 jobs (fg, bg) per page, each on its own CU.
 //
 // Algorithmic bytes: (1 + 2C)*w*h per call (mask + img in, out).
 #include "mrchip_internal.h"
 
 namespace mrchip {
 
-constexpr int OP = 16;   // columns per thread
-
-template <int C>
+template <int C, int P>
 struct RowRegs {
-    uint4 m;        // 16 mask bytes
-    uint4 px[C];    // 16*C image bytes
+    unsigned m[P / 4];          // P mask bytes
+    unsigned px[P * C / 4];     // P*C image bytes
 };
 
-template <int C>
-__device__ __forceinline__ RowRegs<C> load_row_regs(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
-                                                    int y, int x0, bool ok) {
-    RowRegs<C> r;
+template <int C, int P>
+__device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
+                                                       int y, int x0, bool ok) {
+    RowRegs<C, P> r;
     if (ok) {
-        r.m = *reinterpret_cast<const uint4 *>(mask + (size_t)y * mpitch + x0);
-        const uint4 *p = reinterpret_cast<const uint4 *>(img + (size_t)y * ipitch + (size_t)x0 * C);
+        const unsigned *pm = reinterpret_cast<const unsigned *>(mask + (size_t)y * mpitch + x0);
+        const unsigned *pi = reinterpret_cast<const unsigned *>(img + (size_t)y * ipitch + (size_t)x0 * C);
 #pragma unroll
-        for (int i = 0; i < C; i++) r.px[i] = p[i];
+        for (int i = 0; i < P / 4; i++) r.m[i] = pm[i];
+#pragma unroll
+        for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
     } else {
-        r.m = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < C; i++) r.px[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < P / 4; i++) r.m[i] = 0;
+#pragma unroll
+        for (int i = 0; i < P * C / 4; i++) r.px[i] = 0;
     }
     return r;
 }
 
-__device__ __forceinline__ unsigned byte_of(const uint4 &v, int i) {
-    unsigned d = (i >> 2) == 0 ? v.x : (i >> 2) == 1 ? v.y : (i >> 2) == 2 ? v.z : v.w;
-    return (d >> (8 * (i & 3))) & 0xffu;
-}
+// j-th byte of a dword array (j is a compile-time constant after unrolling: never index
+// register arrays dynamically -- hipcc 7.2 miscompiled the dynamic form at the right image edge)
+template <int N>
+__device__ __forceinline__ unsigned byte_at(const unsigned (&v)[N], int j) { return (v[j >> 2] >> (8 * (j & 3))) & 0xffu; }
 
-template <int C>
-__device__ __forceinline__ unsigned px_byte(const uint4 (&px)[C], int j) {   // j-th byte of the 16*C block
-    return byte_of(px[j >> 4], j & 15);
-}
+// val / cnt for 0 <= val <= 255*cnt and cnt <= 5120 (n <= 32): the quotient is <= 255 and its
+// fractional part is a multiple of 1/cnt, so (val + 0.5) * rcp(cnt) truncates to it exactly
+// (val < 2^23 is exact in fp32; margin 0.5/cnt >= 9.7e-5 against an error below 255 * 2^-22 = 6.1e-5).
+__device__ __forceinline__ unsigned div_small(int val, float rc) { return (unsigned)(((float)val + 0.5f) * rc); }
 
-// val / cnt for 0 <= val <= 255*cnt, 1 <= cnt < 2^15: the quotient is <= 255 and its
-// fractional part is a multiple of 1/cnt, so (val + 0.5) * rcp(cnt) truncates exactly
-// (margin 0.5/cnt >> fp32 error of 255 * 2^-22).
-__device__ __forceinline__ unsigned div_small(int val, float rc) {
-    return (unsigned)(((float)val + 0.5f) * rc);
-}
-
-template <int C, int MAXT>
-__global__ __launch_bounds__(MAXT) void optimise_kernel(const uint8_t *__restrict__ mask, int mpitch,
-                                                        const uint8_t *__restrict__ img, int ipitch,
-                                                        uint8_t *out, int opitch, int w, int h, int n, int inv) {
+template <int C, int P, int MAXT>
+__global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // entry for column c lives at index c + npad; npad leading / trailing entries stay zero
-    constexpr int EW = (C == 3) ? 4 : 2;          // dwords per entry
-    unsigned *ent = reinterpret_cast<unsigned *>(smem);
+    const OptJob J = jobs[blockIdx.x];
+    const uint8_t *__restrict__ mask = J.mask;
+    const uint8_t *__restrict__ img = J.img;
+    uint8_t *out = J.out;
+    const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h, n = J.n;
+    const unsigned invb = J.invert ? 1u : 0u;
+
+    constexpr int EW = (C == 3) ? 2 : 1;          // dwords per LDS element
     const int npad = n;
     const int T = blockDim.x;
     const int t = threadIdx.x;
-    const int x0 = t * OP;
-    const int nent = T * OP + 2 * npad;
-    for (int i = t; i < nent * EW; i += T) ent[i] = 0;
+    const int x0 = t * P;
+    const int nent = T * P + 2 * npad;
+    const int nelem = nent + nent / P + 1;
+    unsigned *firA = reinterpret_cast<unsigned *>(smem);
+    unsigned *iirA = firA + (size_t)nelem * EW;
+    for (int i = t; i < 2 * nelem * EW; i += T) firA[i] = 0;
     __syncthreads();
+    auto eidx = [&](int col) { const int e = col + npad; return (e + e / P) * EW; };
 
     const bool act = x0 < w;                       // thread has at least one real column
     unsigned colok = 0;                            // bit i: column x0+i < w
 #pragma unroll
-    for (int i = 0; i < OP; i++) if (x0 + i < w) colok |= 1u << i;
-    const unsigned invb = inv ? 1u : 0u;
+    for (int i = 0; i < P; i++) if (x0 + i < w) colok |= 1u << i;
 
-    int fir[OP][C], firc[OP], iir[OP][C];
+    int fir[P][C], firc[P], iir[P][C];
 #pragma unroll
-    for (int i = 0; i < OP; i++) {
+    for (int i = 0; i < P; i++) {
         firc[i] = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) { fir[i][c] = 0; iir[i][c] = 0; }
     }
-    uint4 prev[C];                                 // output row y-1 (16*C bytes)
+    unsigned prev[P * C / 4];                      // output row y-1
 #pragma unroll
-    for (int c = 0; c < C; c++) prev[c] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < P * C / 4; i++) prev[i] = 0;
 
-    auto fir_apply = [&](const RowRegs<C> &r, int sign) {
+    auto fir_apply = [&](const RowRegs<C, P> &r, int sign) {
 #pragma unroll
-        for (int i = 0; i < OP; i++) {
-            unsigned mb = byte_of(r.m, i);
-            bool on = (((mb != 0) ? 1u : 0u) ^ invb) && ((colok >> i) & 1u);
+        for (int i = 0; i < P; i++) {
+            const unsigned mb = byte_at(r.m, i);
+            const bool on = ((((mb != 0) ? 1u : 0u) ^ invb) != 0) && ((colok >> i) & 1u);
             if (on) {
                 firc[i] += sign;
 #pragma unroll
-                for (int c = 0; c < C; c++) fir[i][c] += sign * (int)px_byte<C>(r.px, i * C + c);
+                for (int c = 0; c < C; c++) fir[i][c] += sign * (int)byte_at(r.px, i * C + c);
             }
         }
     };
 
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C> r = load_row_regs<C>(mask, mpitch, img, ipitch, yy, x0, act);
+        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, x0, act);
         fir_apply(r, +1);
     }
-    // prefetch for y = 0
-    RowRegs<C> r_enter = load_row_regs<C>(mask, mpitch, img, ipitch, n - 1, x0, act && (n - 1 < h) && n >= 1);
-    RowRegs<C> r_leave = load_row_regs<C>(mask, mpitch, img, ipitch, 0, x0, false);
-    RowRegs<C> r_cur = load_row_regs<C>(mask, mpitch, img, ipitch, 0, x0, act);
-    uint4 o_leave[C];
+    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, x0, act && (n - 1 < h) && n >= 1);
+    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, x0, false);
+    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, x0, act);
+    unsigned o_leave[P * C / 4];
 #pragma unroll
-    for (int c = 0; c < C; c++) o_leave[c] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < P * C / 4; i++) o_leave[i] = 0;
 
     for (int y = 0; y < h; y++) {
         // ---- issue next row's loads first (independent of the serial chain) ----
         const int yn = y + 1;
-        RowRegs<C> n_enter = load_row_regs<C>(mask, mpitch, img, ipitch, yn + n - 1, x0, act && (yn + n - 1 < h));
-        RowRegs<C> n_leave = load_row_regs<C>(mask, mpitch, img, ipitch, yn - n - 1, x0, act && (yn - n - 1 >= 0));
-        RowRegs<C> n_cur = load_row_regs<C>(mask, mpitch, img, ipitch, yn, x0, act && (yn < h));
-        uint4 n_oleave[C];
+        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, x0, act && (yn + n - 1 < h));
+        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, x0, act && (yn - n - 1 >= 0));
+        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, x0, act && (yn < h));
+        unsigned n_oleave[P * C / 4];
         {
             const bool ok = act && (yn - n - 1 >= 0);
-            const uint4 *p = reinterpret_cast<const uint4 *>(out + (size_t)max(yn - n - 1, 0) * opitch + (size_t)x0 * C);
+            const unsigned *p = reinterpret_cast<const unsigned *>(out + (size_t)max(yn - n - 1, 0) * opitch + (size_t)x0 * C);
 #pragma unroll
-            for (int c = 0; c < C; c++) n_oleave[c] = ok ? p[c] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < P * C / 4; i++) n_oleave[i] = ok ? p[i] : 0u;
         }
 
         // ---- vertical running sums for row y ----
@@ -144,160 +144,157 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const uint8_t *__restric
         if (y - n - 1 >= 0 && n >= 1) fir_apply(r_leave, -1);     // row y-n-1 leaves (ys = max(0, y-n))
         if (y >= 1 && n >= 1) {
 #pragma unroll
-            for (int i = 0; i < OP; i++)
+            for (int i = 0; i < P; i++)
                 if ((colok >> i) & 1u) {
 #pragma unroll
-                    for (int c = 0; c < C; c++) iir[i][c] += (int)px_byte<C>(prev, i * C + c);
+                    for (int c = 0; c < C; c++) iir[i][c] += (int)byte_at(prev, i * C + c);
                 }
         }
         if (y - n - 1 >= 0 && n >= 1) {
 #pragma unroll
-            for (int i = 0; i < OP; i++)
+            for (int i = 0; i < P; i++)
                 if ((colok >> i) & 1u) {
 #pragma unroll
-                    for (int c = 0; c < C; c++) iir[i][c] -= (int)px_byte<C>(o_leave, i * C + c);
+                    for (int c = 0; c < C; c++) iir[i][c] -= (int)byte_at(o_leave, i * C + c);
                 }
         }
         const int ys = max(0, y - n);
 
         // ---- publish column sums ----
 #pragma unroll
-        for (int i = 0; i < OP; i++) {
-            unsigned *e = ent + (size_t)(x0 + i + npad) * EW;
+        for (int i = 0; i < P; i++) {
+            const int e = eidx(x0 + i);
             if constexpr (C == 3) {
-                uint4 v;
-                v.x = (unsigned)fir[i][0] | ((unsigned)fir[i][1] << 16);
-                v.y = (unsigned)fir[i][2] | ((unsigned)firc[i] << 16);
-                v.z = (unsigned)iir[i][0] | ((unsigned)iir[i][1] << 16);
-                v.w = (unsigned)iir[i][2];
-                *reinterpret_cast<uint4 *>(e) = v;
+                *reinterpret_cast<uint2 *>(firA + e) =
+                    make_uint2((unsigned)fir[i][0] | ((unsigned)fir[i][1] << 16), (unsigned)fir[i][2] | ((unsigned)firc[i] << 16));
+                *reinterpret_cast<uint2 *>(iirA + e) =
+                    make_uint2((unsigned)iir[i][0] | ((unsigned)iir[i][1] << 16), (unsigned)iir[i][2]);
             } else {
-                uint2 v;
-                v.x = (unsigned)fir[i][0] | ((unsigned)firc[i] << 16);
-                v.y = (unsigned)iir[i][0];
-                *reinterpret_cast<uint2 *>(e) = v;
+                firA[e] = (unsigned)fir[i][0] | ((unsigned)firc[i] << 16);
+                iirA[e] = (unsigned)iir[i][0];
             }
         }
         __syncthreads();
 
-        // ---- horizontal sliding windows over the LDS row ----
+        // ---- horizontal sliding windows over the LDS rows ----
         int fs[C], is[C], fc = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) { fs[c] = 0; is[c] = 0; }
         auto add_fir = [&](int col, int sign) {
-            const unsigned *e = ent + (size_t)(col + npad) * EW;
+            const int e = eidx(col);
             if constexpr (C == 3) {
-                uint2 v = *reinterpret_cast<const uint2 *>(e);
+                uint2 v = *reinterpret_cast<const uint2 *>(firA + e);
                 fs[0] += sign * (int)(v.x & 0xffffu); fs[1] += sign * (int)(v.x >> 16);
                 fs[2] += sign * (int)(v.y & 0xffffu); fc += sign * (int)(v.y >> 16);
             } else {
-                unsigned v = e[0];
+                unsigned v = firA[e];
                 fs[0] += sign * (int)(v & 0xffffu); fc += sign * (int)(v >> 16);
             }
         };
         auto add_iir = [&](int col, int sign) {
-            const unsigned *e = ent + (size_t)(col + npad) * EW;
+            const int e = eidx(col);
             if constexpr (C == 3) {
-                uint2 v = *reinterpret_cast<const uint2 *>(e + 2);
+                uint2 v = *reinterpret_cast<const uint2 *>(iirA + e);
                 is[0] += sign * (int)(v.x & 0xffffu); is[1] += sign * (int)(v.x >> 16);
                 is[2] += sign * (int)(v.y & 0xffffu);
             } else {
-                is[0] += sign * (int)e[1];
+                is[0] += sign * (int)iirA[e];
             }
         };
         // window of pixel x0: fir columns [x0-n, x0+n), iir columns [x0-n, x0)
         for (int j = -n; j < n; j++) add_fir(x0 + j, +1);
         for (int j = -n; j < 0; j++) add_iir(x0 + j, +1);
 
-        uint4 res[C];
+        unsigned resb[P * C];
 #pragma unroll
-        for (int c = 0; c < C; c++) res[c] = r_cur.px[c];      // masked pixels keep the image value
-        unsigned resb[OP * C];
-#pragma unroll
-        for (int i = 0; i < OP; i++) {
+        for (int i = 0; i < P; i++) {
             const int x = x0 + i;
             const int xs = max(0, x - n);
             const int cnt = fc + (y - ys) * (x - xs);
-            const unsigned mb = byte_of(r_cur.m, i);
+            const unsigned mb = byte_at(r_cur.m, i);
             const bool masked = (((mb != 0) ? 1u : 0u) ^ invb) != 0;
             const float rc = __frcp_rn((float)max(cnt, 1));
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 unsigned q = cnt > 0 ? div_small(fs[c] + is[c], rc) : 0u;
-                resb[i * C + c] = masked ? px_byte<C>(r_cur.px, i * C + c) : q;
+                resb[i * C + c] = masked ? byte_at(r_cur.px, i * C + c) : q;   // masked pixels keep the image value
             }
-            // slide to pixel x+1
-            add_fir(x + n, +1);
-            add_fir(x - n, -1);
-            add_iir(x, +1);
-            add_iir(x - n, -1);
-        }
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            unsigned d[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int b = c * 16 + q * 4;
-                d[q] = resb[b] | (resb[b + 1] << 8) | (resb[b + 2] << 16) | (resb[b + 3] << 24);
+            if (i + 1 < P) {      // slide to pixel x+1
+                add_fir(x + n, +1);
+                add_fir(x - n, -1);
+                add_iir(x, +1);
+                add_iir(x - n, -1);
             }
-            res[c] = make_uint4(d[0], d[1], d[2], d[3]);
         }
-        // ---- store the row (full vectors inside the image, bytes at the right edge) ----
+        unsigned res[P * C / 4];
+#pragma unroll
+        for (int q = 0; q < P * C / 4; q++)
+            res[q] = (resb[4 * q] & 0xffu) | ((resb[4 * q + 1] & 0xffu) << 8) | ((resb[4 * q + 2] & 0xffu) << 16) |
+                     (resb[4 * q + 3] << 24);
+        // ---- store the row (whole dwords inside the image, bytes at the right edge) ----
         if (act) {
             uint8_t *o = out + (size_t)y * opitch + (size_t)x0 * C;
-            if (x0 + OP <= w) {
+            if (x0 + P <= w) {
 #pragma unroll
-                for (int c = 0; c < C; c++) reinterpret_cast<uint4 *>(o)[c] = res[c];
+                for (int q = 0; q < P * C / 4; q++) reinterpret_cast<unsigned *>(o)[q] = res[q];
             } else {
                 const int nbytes = (w - x0) * C;
 #pragma unroll
-                for (int j = 0; j < OP * C; j++)
+                for (int j = 0; j < P * C; j++)
                     if (j < nbytes) o[j] = (uint8_t)resb[j];
             }
         }
 #pragma unroll
-        for (int c = 0; c < C; c++) prev[c] = res[c];
-        __syncthreads();       // everyone is done reading the LDS row
+        for (int q = 0; q < P * C / 4; q++) prev[q] = res[q];
+        __syncthreads();       // everyone is done reading the LDS rows
 
         r_enter = n_enter; r_leave = n_leave; r_cur = n_cur;
 #pragma unroll
-        for (int c = 0; c < C; c++) o_leave[c] = n_oleave[c];
+        for (int q = 0; q < P * C / 4; q++) o_leave[q] = n_oleave[q];
     }
 }
 
-int launch_optimise(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
-                    uint8_t *out, int opitch, int w, int h, int c, int n, int invert_mask) {
-    if (c != 1 && c != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
+struct OptGeom { int P, T; size_t lds; };
+
+static int opt_geometry(int w, int c, int n, OptGeom *g) {
     // n <= 32 keeps val < 2^23 and cnt <= 5120, the range in which div_small is exact
     if (n < 0 || n > 32) { set_error("optimise: n_size %d outside [0,32]", n); return MRCHIP_E_UNSUPPORTED; }
-    if (w <= 0 || h <= 0) return 0;
-    int T = round_up(cdiv(w, OP), 64);
-    if (T > 1024) { set_error("optimise: width %d > %d not supported", w, 1024 * OP); return MRCHIP_E_UNSUPPORTED; }
-    const int ew = (c == 3) ? 16 : 8;
-    size_t lds = (size_t)(T * OP + 2 * n) * ew;
-    if (lds > 160 * 1024) {
-        set_error("optimise: width %d needs %zu bytes of LDS (> 160 KiB)", w, lds);
-        return MRCHIP_E_UNSUPPORTED;
-    }
-    if ((mpitch & 15) || (ipitch & 15) || (opitch & 15)) { set_error("optimise: pitches must be multiples of 16"); return MRCHIP_E_ARG; }
-    const double alg = (1.0 + 2.0 * c) * w * h;
-#define OPT_LAUNCH(CC, MT, NAME)                                                                        \
+    int P = 4;
+    while (P < 16 && cdiv(w, P) > 1024) P *= 2;
+    int T = round_up(cdiv(w, P), 64);
+    if (T > 1024) { set_error("optimise: width %d > %d not supported", w, 1024 * 16); return MRCHIP_E_UNSUPPORTED; }
+    const int ew = (c == 3) ? 16 : 8;             // FIR + IIR element bytes per column
+    const int nent = T * P + 2 * n;
+    size_t lds = (size_t)(nent + nent / P + 1) * ew;
+    if (lds > 160 * 1024) { set_error("optimise: width %d needs %zu bytes of LDS (> 160 KiB)", w, lds); return MRCHIP_E_UNSUPPORTED; }
+    g->P = P; g->T = T; g->lds = lds;
+    return 0;
+}
+
+// d_jobs: njobs OptJob records in device memory, all with the same w, c (same geometry);
+// n_max = the largest n_size among them (sizes the LDS rows)
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max) {
+    if (c != 1 && c != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
+    if (w <= 0 || h <= 0 || njobs <= 0) return 0;
+    OptGeom g;
+    TRY(opt_geometry(w, c, n_max, &g));
+    const double alg = (1.0 + 2.0 * c) * w * h * njobs;
+#define OPT_LAUNCH(CC, PP, MT, NAME)                                                                     \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_kernel<CC, MT>),            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_kernel<CC, PP, MT>),        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));           \
         LAUNCH(ctx, s, NAME, alg,                                                                       \
-               hipLaunchKernelGGL((optimise_kernel<CC, MT>), dim3(1), dim3(T), lds, s, mask, mpitch,    \
-                                  img, ipitch, out, opitch, w, h, n, invert_mask));                     \
+               hipLaunchKernelGGL((optimise_kernel<CC, PP, MT>), dim3(njobs), dim3(g.T), g.lds, s, d_jobs)); \
     } while (0)
-    if (c == 3) {
-        if (T <= 256) OPT_LAUNCH(3, 256, "optimise_rgb");
-        else if (T <= 512) OPT_LAUNCH(3, 512, "optimise_rgb");
-        else OPT_LAUNCH(3, 1024, "optimise_rgb");
-    } else {
-        if (T <= 256) OPT_LAUNCH(1, 256, "optimise_gray");
-        else if (T <= 512) OPT_LAUNCH(1, 512, "optimise_gray");
-        else OPT_LAUNCH(1, 1024, "optimise_gray");
-    }
+#define OPT_PICK(CC, NAME)                                                          \
+    do {                                                                            \
+        if (g.P == 4) { if (g.T <= 512) OPT_LAUNCH(CC, 4, 512, NAME); else OPT_LAUNCH(CC, 4, 1024, NAME); }   \
+        else if (g.P == 8) OPT_LAUNCH(CC, 8, 1024, NAME);                           \
+        else OPT_LAUNCH(CC, 16, 1024, NAME);                                        \
+    } while (0)
+    if (c == 3) OPT_PICK(3, "optimise_rgb");
+    else OPT_PICK(1, "optimise_gray");
+#undef OPT_PICK
 #undef OPT_LAUNCH
     return 0;
 }

@@ -84,10 +84,13 @@ __device__ __forceinline__ unsigned reduce_multiplier(int cells) {
     return (unsigned)__fdiv_rn(max_int, (float)max_dividend);
 }
 
-__global__ __launch_bounds__(256) void reduce_kernel(const uint8_t *src, int spitch, int w, int h, int c, int fx, int fy,
-                                                     uint8_t *dst, int dpitch, int ow, int oh) {
+__global__ __launch_bounds__(256) void reduce_kernel(const uint8_t *src, int spitch, size_t sstride, int w, int h, int c,
+                                                     int fx, int fy, uint8_t *dst, int dpitch, size_t dstride, int ow,
+                                                     int oh) {
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
     if (ox >= ow) return;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
     const int y0 = oy * fy, y1 = min(h, y0 + fy), x0 = ox * fx, x1 = min(w, x0 + fx);
     const int cells = (y1 - y0) * (x1 - x0);
     const unsigned mult = reduce_multiplier(cells), amend = (unsigned)cells / 2;
@@ -105,10 +108,13 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int spitch, int h, uint8_t *dst, int dpitch,
-                                                       int ow, const int32_t *bounds, const int32_t *kk, int ksize) {
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
+                                                       uint8_t *dst, int dpitch, size_t dstride, int ow,
+                                                       const int32_t *bounds, const int32_t *kk, int ksize) {
     const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (xx >= ow) return;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
     const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
     const int32_t *k = kk + (size_t)xx * ksize;
     const uint8_t *row = src + (size_t)y * spitch + (size_t)xmin * C;
@@ -124,11 +130,13 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int s
     for (int ch = 0; ch < C; ch++) dst[(size_t)y * dpitch + (size_t)xx * C + ch] = clip8(ss[ch]);
 }
 
-__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *src, int spitch, int row_bytes, uint8_t *dst,
-                                                       int dpitch, int oh, const int32_t *bounds, const int32_t *kk,
-                                                       int ksize) {
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *src, int spitch, size_t sstride, int row_bytes,
+                                                       uint8_t *dst, int dpitch, size_t dstride, int oh,
+                                                       const int32_t *bounds, const int32_t *kk, int ksize) {
     const int j = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
     if (j >= row_bytes) return;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
     const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
     const int32_t *k = kk + (size_t)yy * ksize;
     int ss = 1 << 21;
@@ -163,43 +171,47 @@ size_t ThumbPlan_table_bytes(const ThumbPlan &p) {
 }
 
 // d_tables: device copy of [bh_, kh_, bv_, kv_] in that order (int32), made by the caller.
-// scratch1: rw*rh*c (reduce output, if any); scratch2: ow*rh*c (horizontal pass output)
-int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, const uint8_t *src, int spitch,
-                          uint8_t *dst, int dpitch, const int32_t *d_tables, uint8_t *scratch1, uint8_t *scratch2) {
+// scratch1: rw*rh*c per page (reduce output, if any); scratch2: ow*rh*c per page (horizontal pass output)
+int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
+                          const int32_t *d_tables, Plane scratch1, Plane scratch2, int npages) {
     const int c = p.c;
     if (!p.changed) {
-        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, (size_t)p.w * c, p.h, hipMemcpyDeviceToDevice, s));
+        for (int i = 0; i < npages; i++)
+            HIP_TRY(hipMemcpy2DAsync(dst.page(i), dst.pitch, src.page(i), src.pitch, (size_t)p.w * c, p.h,
+                                     hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    const double alg = (double)c * p.w * p.h + (double)c * p.ow * p.oh;
-    const uint8_t *cur = src;
-    int cpitch = spitch, cw = p.w, ch_ = p.h;
-    if (p.fx > 1 || p.fy > 1) {
+    const double alg = ((double)c * p.w * p.h + (double)c * p.ow * p.oh) * npages;
+    Plane cur = src;
+    int cw = p.w, ch_ = p.h;
+    const bool red = p.fx > 1 || p.fy > 1;
+    if (red) {
         LAUNCH(ctx, s, "thumb_reduce", alg,
-               hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(p.rw, 256), p.rh), dim3(256), 0, s, cur, cpitch, cw, ch_, c,
-                                  p.fx, p.fy, scratch1, p.rw * c, p.rw, p.rh));
-        cur = scratch1; cpitch = p.rw * c; cw = p.rw; ch_ = p.rh;
+               hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(p.rw, 256), p.rh, npages), dim3(256), 0, s, cur.p, cur.pitch,
+                                  cur.stride, cw, ch_, c, p.fx, p.fy, scratch1.p, scratch1.pitch, scratch1.stride, p.rw, p.rh));
+        cur = scratch1; cw = p.rw; ch_ = p.rh;
     }
     const int32_t *d_bh = d_tables, *d_kh = d_bh + p.bh_.size(), *d_bv = d_kh + p.kh_.size(), *d_kv = d_bv + p.bv_.size();
     if (p.need_h) {
-        uint8_t *o = p.need_v ? scratch2 : dst;
-        int opitch = p.need_v ? p.ow * c : dpitch;
+        Plane o = p.need_v ? scratch2 : dst;
         if (c == 3)
-            LAUNCH(ctx, s, "thumb_resize_h", p.fx > 1 || p.fy > 1 ? 0.0 : alg,
-                   hipLaunchKernelGGL(resize_h_kernel<3>, dim3(cdiv(p.ow, 256), ch_), dim3(256), 0, s, cur, cpitch, ch_, o,
-                                      opitch, p.ow, d_bh, d_kh, p.ksh));
+            LAUNCH(ctx, s, "thumb_resize_h", red ? 0.0 : alg,
+                   hipLaunchKernelGGL(resize_h_kernel<3>, dim3(cdiv(p.ow, 256), ch_, npages), dim3(256), 0, s, cur.p, cur.pitch,
+                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
         else
-            LAUNCH(ctx, s, "thumb_resize_h", p.fx > 1 || p.fy > 1 ? 0.0 : alg,
-                   hipLaunchKernelGGL(resize_h_kernel<1>, dim3(cdiv(p.ow, 256), ch_), dim3(256), 0, s, cur, cpitch, ch_, o,
-                                      opitch, p.ow, d_bh, d_kh, p.ksh));
-        cur = o; cpitch = opitch; cw = p.ow;
+            LAUNCH(ctx, s, "thumb_resize_h", red ? 0.0 : alg,
+                   hipLaunchKernelGGL(resize_h_kernel<1>, dim3(cdiv(p.ow, 256), ch_, npages), dim3(256), 0, s, cur.p, cur.pitch,
+                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
+        cur = o; cw = p.ow;
     }
     if (p.need_v) {
-        LAUNCH(ctx, s, "thumb_resize_v", 0.0,
-               hipLaunchKernelGGL(resize_v_kernel, dim3(cdiv(cw * c, 256), p.oh), dim3(256), 0, s, cur, cpitch, cw * c, dst,
-                                  dpitch, p.oh, d_bv, d_kv, p.ksv));
-    } else if (cur != dst) {
-        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, cur, cpitch, (size_t)cw * c, ch_, hipMemcpyDeviceToDevice, s));
+        LAUNCH(ctx, s, "thumb_resize_v", (red || p.need_h) ? 0.0 : alg,
+               hipLaunchKernelGGL(resize_v_kernel, dim3(cdiv(cw * c, 256), p.oh, npages), dim3(256), 0, s, cur.p, cur.pitch,
+                                  cur.stride, cw * c, dst.p, dst.pitch, dst.stride, p.oh, d_bv, d_kv, p.ksv));
+    } else if (cur.p != dst.p) {
+        for (int i = 0; i < npages; i++)
+            HIP_TRY(hipMemcpy2DAsync(dst.page(i), dst.pitch, cur.page(i), cur.pitch, (size_t)cw * c, ch_,
+                                     hipMemcpyDeviceToDevice, s));
     }
     return 0;
 }

@@ -50,12 +50,30 @@ __device__ __forceinline__ T dwt_point(const Db2<T> &F, int N, int i, Get get) {
     return sum;
 }
 
+constexpr int DIG = 11;
+constexpr int NBIN = 1 << DIG;
+
+struct SelState {
+    unsigned long long prefix[2];
+    unsigned long long rank[2];
+    unsigned long long count;
+    unsigned hist[2][NBIN];
+    double sigma;
+};
+
 template <class T>
-__global__ __launch_bounds__(256) void dwt_dd_kernel(const uint8_t *src, int pitch, int w, int h, int as_bool,
-                                                     Db2<T> F, T *dd, int w2, int h2) {
+__global__ __launch_bounds__(256) void dwt_dd_kernel(const uint8_t *src, int pitch, size_t sstride, int w, int h,
+                                                     int as_bool, Db2<T> F, char *scratch, size_t scratch_stride,
+                                                     size_t dd_off, int w2, int h2) {
     const int m = blockIdx.x * 256 + threadIdx.x;   // column of dd
     const int k = blockIdx.y;                       // row of dd
+    if (blockIdx.x == 0 && blockIdx.y == 0) {       // reset this page's selection state
+        unsigned *z = reinterpret_cast<unsigned *>(scratch + (size_t)blockIdx.z * scratch_stride);
+        for (int i = threadIdx.x; i < (int)(sizeof(SelState) / 4); i += 256) z[i] = 0;
+    }
     if (m >= w2) return;
+    src += (size_t)blockIdx.z * sstride;
+    T *dd = reinterpret_cast<T *>(scratch + (size_t)blockIdx.z * scratch_stride + dd_off);
     auto px = [&](int yy, int xx) -> T {
         unsigned v = src[(size_t)yy * pitch + xx];
         return as_bool ? (T)(v ? 1 : 0) : (T)v;
@@ -82,23 +100,14 @@ template <> struct Key<double> {
     __device__ static double val(U k) { return __longlong_as_double((long long)k); }
 };
 
-constexpr int DIG = 11;
-constexpr int NBIN = 1 << DIG;
-
-struct SelState {
-    unsigned long long prefix[2];
-    unsigned long long rank[2];
-    unsigned long long count;
-    unsigned hist[2][NBIN];
-    double sigma;
-};
-
 // histogram of the digit at `shift` (width `bits`) among the non-zero |dd| whose higher
 // bits equal prefix[r]
 template <class T>
-__global__ __launch_bounds__(256) void sel_hist_kernel(const T *dd, size_t n, SelState *st, int shift, int bits,
-                                                       int first) {
+__global__ __launch_bounds__(256) void sel_hist_kernel(char *scratch, size_t scratch_stride, size_t dd_off, size_t n,
+                                                       int shift, int bits, int first) {
     using U = typename Key<T>::U;
+    SelState *st = reinterpret_cast<SelState *>(scratch + (size_t)blockIdx.y * scratch_stride);
+    const T *dd = reinterpret_cast<const T *>(scratch + (size_t)blockIdx.y * scratch_stride + dd_off);
     __shared__ unsigned lh[2][NBIN];
     for (int i = threadIdx.x; i < 2 * NBIN; i += 256) (&lh[0][0])[i] = 0;
     __syncthreads();
@@ -121,71 +130,104 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const T *dd, size_t n, Se
 }
 
 // one wave: locate the bins of both ranks, extend the prefixes, clear the histograms;
-// on the last digit produce sigma
+// on the last digit produce sigma.  Lane l owns bins [l*per, (l+1)*per).
 template <class T>
-__global__ __launch_bounds__(64) void sel_scan_kernel(SelState *st, int bits, int first, int last) {
+__global__ __launch_bounds__(64) void sel_scan_kernel(char *scratch, size_t scratch_stride, int bits, int first, int last,
+                                                      double *d_sigma) {
     using U = typename Key<T>::U;
-    if (threadIdx.x != 0) return;
+    SelState *st = reinterpret_cast<SelState *>(scratch + (size_t)blockIdx.x * scratch_stride);
+    const int lane = threadIdx.x;
     const int nb = 1 << bits;
+    const int per = (nb + 63) / 64;
+    unsigned long long lsum[2] = {0, 0};
+    for (int r = 0; r < 2; r++)
+        for (int b = lane * per; b < min(nb, (lane + 1) * per); b++) lsum[r] += st->hist[r][b];
+    unsigned long long count = st->count, rank[2] = {st->rank[0], st->rank[1]}, prefix[2] = {st->prefix[0], st->prefix[1]};
     if (first) {
-        unsigned long long m = 0;
-        for (int b = 0; b < nb; b++) m += st->hist[0][b];
-        st->count = m;
-        st->prefix[0] = st->prefix[1] = 0;
-        if (m == 0) { st->rank[0] = st->rank[1] = 0; }
-        else if (m & 1) { st->rank[0] = st->rank[1] = m / 2; }
-        else { st->rank[0] = m / 2 - 1; st->rank[1] = m / 2; }
+        unsigned long long m = lsum[0];
+        for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+        count = m;
+        prefix[0] = prefix[1] = 0;
+        if (m == 0) { rank[0] = rank[1] = 0; }
+        else if (m & 1) { rank[0] = rank[1] = m / 2; }
+        else { rank[0] = m / 2 - 1; rank[1] = m / 2; }
     }
-    if (st->count) {
+    if (count) {
         for (int r = 0; r < 2; r++) {
-            unsigned long long cum = 0, rank = st->rank[r];
-            int b = 0;
-            for (; b < nb; b++) {
-                unsigned c = st->hist[r][b];
-                if (rank < cum + c) break;
-                cum += c;
+            // exclusive prefix of the lane sums
+            unsigned long long inc = lsum[r];
+            for (int off = 1; off < 64; off <<= 1) {
+                unsigned long long v = __shfl_up(inc, off);
+                if (lane >= off) inc += v;
             }
-            st->rank[r] = rank - cum;
-            st->prefix[r] = (st->prefix[r] << bits) | (unsigned long long)b;
+            const unsigned long long exc = inc - lsum[r];
+            const bool mine = rank[r] >= exc && rank[r] < inc;       // exactly one lane
+            unsigned long long nr = 0, bsel = 0;
+            if (mine) {
+                unsigned long long cum = exc;
+                int b = lane * per;
+                for (; b < min(nb, (lane + 1) * per); b++) {
+                    unsigned c = st->hist[r][b];
+                    if (rank[r] < cum + c) break;
+                    cum += c;
+                }
+                nr = rank[r] - cum;
+                bsel = (unsigned long long)b;
+            }
+            const unsigned long long mask = __ballot(mine);
+            const int src = __ffsll((long long)mask) - 1;
+            nr = __shfl(nr, src);
+            bsel = __shfl(bsel, src);
+            rank[r] = nr;
+            prefix[r] = (prefix[r] << bits) | bsel;
         }
     }
-    for (int i = 0; i < 2 * NBIN; i++) (&st->hist[0][0])[i] = 0;
-    if (last) {
-        if (st->count == 0) {
-            st->sigma = __longlong_as_double(0x7ff8000000000000LL);       // NaN: median of nothing
-        } else {
-            T a = Key<T>::val((U)st->prefix[0]), b = Key<T>::val((U)st->prefix[1]);
-            T med = (st->count & 1) ? a : (T)(add_rn(a, b) / (T)2);        // numpy: mean of the two middle values
-            st->sigma = (double)med / 0.6744897501960817;                 // scipy.stats.norm.ppf(0.75)
+    __syncthreads();
+    for (int i = lane; i < 2 * NBIN; i += 64) (&st->hist[0][0])[i] = 0;
+    if (lane == 0) {
+        st->count = count;
+        st->rank[0] = rank[0]; st->rank[1] = rank[1];
+        st->prefix[0] = prefix[0]; st->prefix[1] = prefix[1];
+        if (last) {
+            if (count == 0) {
+                st->sigma = __longlong_as_double(0x7ff8000000000000LL);       // NaN: median of nothing
+            } else {
+                T a = Key<T>::val((U)prefix[0]), b = Key<T>::val((U)prefix[1]);
+                T med = (count & 1) ? a : (T)(add_rn(a, b) / (T)2);           // numpy: mean of the two middle values
+                st->sigma = (double)med / 0.6744897501960817;                 // scipy.stats.norm.ppf(0.75)
+            }
+            d_sigma[blockIdx.x] = st->sigma;
         }
     }
 }
 
+static size_t dd_offset() { return (sizeof(SelState) + 255) & ~(size_t)255; }
+
 template <class T>
-static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h, int as_bool,
-                     T *dd, SelState *st, double alg) {
+static int run_sigma(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int as_bool, char *scratch,
+                     size_t scratch_stride, double *d_sigma, int npages, double alg) {
     static const double HI[4] = {-0.48296291314453416, 0.8365163037378079, -0.2241438680420134,
                                  -0.12940952255126037};
     Db2<T> F;
     for (int i = 0; i < 4; i++) F.f[i] = (T)HI[i];
     const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
-    HIP_TRY(hipMemsetAsync(st, 0, sizeof(SelState), s));
     LAUNCH(ctx, s, sizeof(T) == 4 ? "dwt_dd_f32" : "dwt_dd_f64", alg,
-           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(w2, 256), h2), dim3(256), 0, s, src, pitch, w, h, as_bool,
-                              F, dd, w2, h2));
+           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(w2, 256), h2, npages), dim3(256), 0, s, src.p, src.pitch,
+                              src.stride, w, h, as_bool, F, scratch, scratch_stride, dd_offset(), w2, h2));
     const size_t n = (size_t)w2 * h2;
-    const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+    const int blocks = (int)std::min<size_t>(npages > 8 ? 64 : 512, (n + 255) / 256);
     int shift = Key<T>::BITS;
     int first = 1;
     while (shift > 0) {
-        int bits = shift >= DIG ? DIG : shift;
-        if (shift % DIG != 0 && shift == Key<T>::BITS) bits = DIG;      // top digit is a full one
+        const int bits = shift >= DIG ? DIG : shift;
         shift -= bits;
         const int last = shift == 0;
         LAUNCH(ctx, s, "median_hist", 0.0,
-               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks), dim3(256), 0, s, dd, n, st, shift, bits, first));
+               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks, npages), dim3(256), 0, s, scratch, scratch_stride,
+                                  dd_offset(), n, shift, bits, first));
         LAUNCH(ctx, s, "median_scan", 0.0,
-               hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(1), dim3(64), 0, s, st, bits, first, last));
+               hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(npages), dim3(64), 0, s, scratch, scratch_stride, bits, first,
+                                  last, d_sigma));
         first = 0;
     }
     return 0;
@@ -193,20 +235,15 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pit
 
 size_t sigma_scratch_bytes(int w, int h, int kind) {
     const size_t n = (size_t)((w + 3) / 2) * ((h + 3) / 2);
-    return sizeof(SelState) + 256 + n * (kind ? sizeof(double) : sizeof(float));
+    return ((dd_offset() + n * (kind ? sizeof(double) : sizeof(float)) + 255) & ~(size_t)255);
 }
 
-// scratch: sigma_scratch_bytes(w,h,kind) bytes, 256-byte aligned.  The result lands in
-// *d_sigma (device memory) when the stream reaches it.
-int launch_estimate_sigma_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h,
-                                  int kind, double *d_sigma, void *scratch) {
+int launch_estimate_sigma_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int kind, double *d_sigma,
+                                void *scratch, size_t scratch_stride, int npages) {
     if (w <= 0 || h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
-    SelState *st = reinterpret_cast<SelState *>(scratch);
-    char *ddp = reinterpret_cast<char *>(scratch) + ((sizeof(SelState) + 255) & ~(size_t)255);
-    if (kind == 0) TRY(run_sigma<float>(ctx, s, src, pitch, w, h, 0, reinterpret_cast<float *>(ddp), st, 1.0 * w * h));
-    else TRY(run_sigma<double>(ctx, s, src, pitch, w, h, 1, reinterpret_cast<double *>(ddp), st, 1.0 * w * h));
-    HIP_TRY(hipMemcpyAsync(d_sigma, &st->sigma, sizeof(double), hipMemcpyDeviceToDevice, s));
-    return 0;
+    char *sc = reinterpret_cast<char *>(scratch);
+    if (kind == 0) return run_sigma<float>(ctx, s, src, w, h, 0, sc, scratch_stride, d_sigma, npages, 1.0 * w * h * npages);
+    return run_sigma<double>(ctx, s, src, w, h, 1, sc, scratch_stride, d_sigma, npages, 1.0 * w * h * npages);
 }
 
 }  // namespace mrchip

@@ -158,13 +158,24 @@ enum SauvolaFlags {
 int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
                    int ww, int wh, double k, double R, int flags);
 
-int launch_luma601(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int rgb_pitch,
-                   uint8_t *gray, int gray_pitch, int w, int h);
+// a plane of a page batch: page i, row y starts at p + i*stride + y*pitch
+struct Plane {
+    uint8_t *p = nullptr;
+    int pitch = 0;
+    size_t stride = 0;
+    uint8_t *page(int i) const { return p + (size_t)i * stride; }
+};
+
+int launch_luma601(mrchip_ctx *ctx, hipStream_t s, Plane rgb, Plane gray, int w, int h, int npages);
 
 
-int launch_optimise(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int mpitch,
-                    const uint8_t *img, int ipitch, uint8_t *out, int opitch,
-                    int w, int h, int c, int n, int invert_mask);
+struct OptJob {
+    const uint8_t *mask; int mpitch;
+    const uint8_t *img; int ipitch;
+    uint8_t *out; int opitch;
+    int w, h, n, invert;
+};
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max);
 
 
 // hOCR: commit chosen thresholds into the mask in list order
@@ -174,9 +185,11 @@ struct HocrBox {
     const uint8_t *th;       // polarity A scratch (pixel (0,0) of the box)
     const uint8_t *thi;      // polarity B scratch
     int pitch;
+    uint8_t *mask;           // row 0 of the page's mask
+    int mpitch;
+    int page_end;            // index one past the last box of the same page
 };
-int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int mpitch,
-                       const HocrBox *d_boxes, int nb, int maxw, int maxh, double area);
+int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area);
 
 // thumbnail plan: host-side size rule + fixed-point coefficient tables
 struct ThumbPlan {
@@ -190,15 +203,21 @@ struct ThumbPlan {
 };
 int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h);
 size_t ThumbPlan_table_bytes(const ThumbPlan &p);
-int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, const uint8_t *src, int spitch,
-                          uint8_t *dst, int dpitch, const int32_t *d_tables, uint8_t *scratch1, uint8_t *scratch2);
+// dst: page i at dst + i*dstride (tight rows of dpitch bytes); scratch1/2 likewise with their strides
+int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
+                          const int32_t *d_tables, Plane scratch1, Plane scratch2, int npages);
 size_t sigma_scratch_bytes(int w, int h, int kind);
-int launch_estimate_sigma_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int pitch, int w, int h,
-                                  int kind, double *d_sigma, void *scratch);
-int launch_gaussian_u8_scratch(mrchip_ctx *ctx, hipStream_t s, const uint8_t *src, int spitch, uint8_t *dst, int dpitch,
-                               int w, int h, const double *h_weights, int radius, float *tmp, int tpitch);
-int launch_denoise_scratch(mrchip_ctx *ctx, hipStream_t s, uint8_t *mask, int pitch, int w, int h, int mincnt, int n,
-                           unsigned *bits);
+// page i: crop at src.page(i), scratch at scratch + i*scratch_stride, result in d_sigma[i]
+int launch_estimate_sigma_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int kind, double *d_sigma,
+                                void *scratch, size_t scratch_stride, int npages);
+constexpr int GMAXR = 60;
+struct GaussW { double w[2 * GMAXR + 1]; int radius; int pad_; };
+// d_weights: npages GaussW records (radius 0 = identity); tmp: page i at tmp + i*tstride floats
+int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
+                          float *tmp, int tpitch, size_t tstride, int npages);
+// bits: page i at bits + i*bits_stride dwords
+int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
+                         size_t bits_stride, int npages);
 size_t denoise_scratch_bytes(int w, int h);
 
 // host logic

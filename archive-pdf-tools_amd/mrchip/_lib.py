@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmrchip.so')
 
+MAX_TAPS = 128        # MRCHIP_MAX_TAPS
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
@@ -55,6 +56,20 @@ SIGNATURES = {
     'mrchip_page_box_decisions': (C.c_int, [vp, i32p, C.c_int]),
     'mrchip_page_device_ptrs': (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t),
                                           C.POINTER(vp), C.POINTER(vp)]),
+    'mrchip_batch_create': (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mrchip_batch_destroy': (None, [vp]),
+    'mrchip_batch_upload': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_set_boxes': (C.c_int, [vp, C.c_int, i32p, C.c_int]),
+    'mrchip_batch_mask_begin': (C.c_int, [vp, C.c_int]),
+    'mrchip_batch_sigmas': (C.c_int, [vp, f64p]),
+    'mrchip_batch_mask_finish': (C.c_int, [vp, f64p, intp, C.c_int]),
+    'mrchip_batch_download_mask': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_layers': (C.c_int, [vp, C.c_int, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
+    'mrchip_batch_download_layer': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
+    'mrchip_batch_sync': (C.c_int, [vp]),
+    'mrchip_batch_box_decisions': (C.c_int, [vp, C.c_int, i32p, C.c_int]),
+    'mrchip_batch_device_ptrs': (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                           C.POINTER(vp), C.POINTER(vp)]),
     'mrchip_prof_enable': (C.c_int, [vp, C.c_int]),
     'mrchip_prof_reset': (C.c_int, [vp]),
     'mrchip_prof_count': (C.c_int, [vp]),

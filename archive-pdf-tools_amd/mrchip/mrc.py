@@ -212,6 +212,115 @@ class _Page:
         return d[:nb].tolist()
 
 
+class Batch:
+    """mrchip_batch handle: N same-sized pages resident on the device, every stage of
+    create_mrc_hocr_components one launch over the whole batch."""
+
+    def __init__(self, ctx, npages, w, h, c):
+        self.lib = _lib.load()
+        self.ctx = ctx
+        self.n, self.w, self.h, self.c = npages, w, h, c
+        self._h = self.lib.mrchip_batch_create(ctx.handle, npages, w, h, c)
+        if not self._h:
+            raise _lib.MrchipError('mrchip_batch_create: %s' % _lib.last_error())
+        self._wtab = np.zeros((npages, _lib.MAX_TAPS), dtype=np.float64)
+        self._radius = np.zeros(npages, dtype=np.int32)
+
+    def close(self):
+        if self._h:
+            self.lib.mrchip_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, page, arr):
+        arr = _lib.as_u8(arr)
+        _lib.check(self.lib.mrchip_batch_upload(self._h, page, _lib.ptr(arr)), 'mrchip_batch_upload')
+
+    def set_boxes(self, page, boxes):
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+        _lib.check(self.lib.mrchip_batch_set_boxes(self._h, page, _lib.ptr(boxes, _lib.i32p) if len(boxes) else None,
+                                                   len(boxes)), 'mrchip_batch_set_boxes')
+
+    def mask_begin(self, window):
+        _lib.check(self.lib.mrchip_batch_mask_begin(self._h, window), 'mrchip_batch_mask_begin')
+
+    def sigmas(self):
+        s = np.zeros(self.n, dtype=np.float64)
+        _lib.check(self.lib.mrchip_batch_sigmas(self._h, _lib.ptr(s, _lib.f64p)), 'mrchip_batch_sigmas')
+        return s
+
+    def mask_finish(self, sigmas, denoise_fast=True):
+        """Builds the per-page Gaussian tables on the host exactly like scipy and enqueues phase B."""
+        for i, s in enumerate(sigmas):
+            if s > 1.0:
+                wts, r = gaussian_weights(s * 0.1)
+                self._wtab[i, :len(wts)] = wts
+                self._radius[i] = r
+            else:
+                self._radius[i] = 0
+        _lib.check(self.lib.mrchip_batch_mask_finish(self._h, _lib.ptr(self._wtab, _lib.f64p),
+                                                     _lib.ptr(self._radius, _lib.intp), 1 if denoise_fast else 0),
+                   'mrchip_batch_mask_finish')
+
+    def layers(self, fg_downsample=None, bg_downsample=None, which=3):
+        fw, fh, bw, bh, ts = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.lib.mrchip_batch_layers(self._h, which, float(fg_downsample or 0.0), float(bg_downsample or 0.0),
+                                                C.byref(fw), C.byref(fh), C.byref(bw), C.byref(bh), C.byref(ts)),
+                   'mrchip_batch_layers')
+        return (fw.value, fh.value), (bw.value, bh.value), ts.value
+
+    def download_mask(self, page):
+        m = np.empty((self.h, self.w), dtype=np.uint8)
+        _lib.check(self.lib.mrchip_batch_download_mask(self._h, page, _lib.ptr(m)), 'mrchip_batch_download_mask')
+        return m.view(np.bool_)
+
+    def download_layer(self, page, is_bg, size):
+        ow, oh = size
+        out = np.empty((oh, ow) if self.c == 1 else (oh, ow, 3), dtype=np.uint8)
+        _lib.check(self.lib.mrchip_batch_download_layer(self._h, page, 1 if is_bg else 0, _lib.ptr(out)),
+                   'mrchip_batch_download_layer')
+        return out
+
+    def box_decisions(self, page, nb):
+        d = np.zeros(max(nb, 1), dtype=np.int32)
+        _lib.check(self.lib.mrchip_batch_box_decisions(self._h, page, _lib.ptr(d, _lib.i32p), nb))
+        return d[:nb].tolist()
+
+    def sync(self):
+        _lib.check(self.lib.mrchip_batch_sync(self._h), 'mrchip_batch_sync')
+
+
+def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
+                    denoise_mask=DENOISE_FAST, ctx=None):
+    """Batch form of create_mrc_hocr_components for same-sized pages: returns a list of
+    (mask, fg, bg) tuples equal to what the generator yields page by page."""
+    arrs = [_image_to_array(im) for im in images]
+    h, w = arrs[0].shape[:2]
+    c = 1 if arrs[0].ndim == 2 else 3
+    if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
+        raise ValueError('Invalid denoise option:', denoise_mask)
+    ctx = ctx or _lib.default_context()
+    b = Batch(ctx, len(arrs), w, h, c)
+    try:
+        for i, (a, hocr) in enumerate(zip(arrs, hocr_list)):
+            if a.shape[:2] != (h, w) or (1 if a.ndim == 2 else 3) != c:
+                raise ValueError('decompose_pages needs same-sized pages of one mode')
+            b.upload(i, a)
+            b.set_boxes(i, hocr_boxes(hocr, w, h, downsample))
+        b.mask_begin(_window_size(dpi))
+        b.mask_finish(b.sigmas(), denoise_mask == DENOISE_FAST)
+        fgs, bgs, _ = b.layers(fg_downsample, bg_downsample)
+        return [(b.download_mask(i), b.download_layer(i, 0, fgs), b.download_layer(i, 1, bgs))
+                for i in range(len(arrs))]
+    finally:
+        b.close()
+
+
 def _image_to_array(image):
     """(array uint8 [h,w] or [h,w,3], had_grey_conversion_mode) from a PIL image or ndarray."""
     if hasattr(image, 'mode'):

@@ -106,22 +106,17 @@ def main():
 
     host_pages = make_pages(DISTINCT, rank)
     window = 51                                    # dpi=None (bin/compress-pdf-images:66-70)
-    pages = []
+    batch = mrc.Batch(ctx, a.pages, W, H, C)
     for i in range(a.pages):
         img, hocr, boxes = host_pages[i % DISTINCT]
-        pg = mrc._Page(ctx, W, H, C)
-        pg.upload(img)
-        pages.append((pg, boxes))
+        batch.upload(i, img)
+        batch.set_boxes(i, boxes)
     ctx.sync()
 
     def step():
-        for pg, boxes in pages:
-            pg.mask_begin(boxes, window)
-        for pg, boxes in pages:
-            s = pg.sigma()
-            pg.mask_finish(s, True)
-            pg.layer(0, None)
-            pg.layer(1, BG_DOWNSAMPLE)
+        batch.mask_begin(window)                       # luma, hOCR-box thresholds, noise estimate
+        batch.mask_finish(batch.sigmas(), True)        # host: Gaussian tables; decisions, blur, Sauvola, denoise
+        batch.layers(None, BG_DOWNSAMPLE)              # fg + bg optimise (one launch), bg thumbnail
 
     def barrier():
         ctx.sync()
@@ -151,8 +146,7 @@ def main():
     # untimed: parity evidence + PCIe-inclusive drop-in rate on rank 0
     extra = {}
     if rank == 0:
-        pg, boxes = pages[0]
-        mask = pg.download_mask()
+        mask = batch.download_mask(0)
         try:
             with open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')) as f:
                 dg = json.load(f)['c2_dpiNone']
@@ -197,8 +191,7 @@ def main():
         }
         line.update(extra)
         print(json.dumps(line))
-    for pg, _ in pages:
-        pg.close()
+    batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,6 +40,11 @@ enum {
 
 typedef struct mrchip_ctx mrchip_ctx;
 typedef struct mrchip_page mrchip_page;
+typedef struct mrchip_batch mrchip_batch;
+
+/* Row length of the per-page Gaussian weight tables handed to *_mask_finish
+ * (2*radius+1 <= 121 entries used, radius <= 60). */
+#define MRCHIP_MAX_TAPS 128
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int mrchip_abi_version(void);
@@ -139,6 +144,32 @@ int mrchip_page_box_decisions(mrchip_page *pg, int32_t *decisions, int nb);
 /* device pointers for zero-copy consumers (mask [h][pitch], layer tight) */
 int mrchip_page_device_ptrs(mrchip_page *pg, void **img, void **mask, size_t *mask_pitch,
                             void **fg, void **bg);
+
+/* ---- page batches: N same-sized pages, every stage one launch over the batch ---
+ * The unit recode.py's page loop (recode.py:291) would hand over when it
+ * decomposes several pages at once; the single-page handle above is a batch of
+ * one.  Calls mirror the page calls; `page` indexes the batch. */
+mrchip_batch *mrchip_batch_create(mrchip_ctx *ctx, int npages, int w, int h, int channels);
+void mrchip_batch_destroy(mrchip_batch *b);
+int mrchip_batch_upload(mrchip_batch *b, int page, const uint8_t *img);
+/* filtered hOCR line boxes of one page (mrc.py:198-221 is host logic), list order */
+int mrchip_batch_set_boxes(mrchip_batch *b, int page, const int32_t *boxes, int nb);
+int mrchip_batch_mask_begin(mrchip_batch *b, int window);
+/* waits for phase A; sigma_est[npages] (mrc.py:305) */
+int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est);
+/* weights: npages rows of MRCHIP_MAX_TAPS doubles (row i used iff sigma_est[i] > 1),
+ * radius[npages]; both NULL = build the tables here with libm's exp */
+int mrchip_batch_mask_finish(mrchip_batch *b, const double *weights, const int *radius, int denoise_fast);
+int mrchip_batch_download_mask(mrchip_batch *b, int page, uint8_t *mask);
+/* which: 1 = fg, 2 = bg, 3 = both (one launch).  downsample <= 0: none.
+ * too_small: bit 0 fg, bit 1 bg ('too-small-to-downsample', mrc.py:429-431, 463-465) */
+int mrchip_batch_layers(mrchip_batch *b, int which, double fg_downsample, double bg_downsample,
+                        int *fg_w, int *fg_h, int *bg_w, int *bg_h, int *too_small);
+int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_bg, uint8_t *out);
+int mrchip_batch_sync(mrchip_batch *b);
+int mrchip_batch_box_decisions(mrchip_batch *b, int page, int32_t *decisions, int nb);
+int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask, size_t *mask_pitch,
+                             void **fg, void **bg);
 
 /* ---- measurement --------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the stream each kernel is launched on.
