@@ -67,18 +67,20 @@ struct mrchip_batch {
 
 // control block layout (device + pinned mirror)
 struct CtrlLayout {
-    size_t sigma, box_sigma, counts, jobs, pjobs, boxes, gauss, optjobs, total;
+    size_t sigma, box_sigma, counts, jobs, pjobs, boxes, gauss, optjobs, sigjobs, boxsigjobs, total;
     CtrlLayout(int npages, int nb) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t r = o; o = (o + bytes + 63) & ~(size_t)63; return r; };
         sigma = take((size_t)npages * 8);
-        box_sigma = take(16);
+        box_sigma = take((size_t)nb * 16 + 16);
         counts = take((size_t)nb * 8);
         jobs = take((size_t)nb * sizeof(SauvolaJob));
         pjobs = take((size_t)npages * sizeof(SauvolaJob));
         boxes = take((size_t)nb * sizeof(HocrBox));
         gauss = take((size_t)npages * sizeof(GaussW));
         optjobs = take((size_t)npages * 2 * sizeof(OptJob));
+        sigjobs = take((size_t)npages * sizeof(SigJob));
+        boxsigjobs = take((size_t)nb * 2 * sizeof(SigJob));
         total = o + 64;
     }
 };
@@ -229,11 +231,18 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
         HIP_TRY(hipMemcpyAsync(b->hctrl + L.counts, dcounts, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
     }
     // ---- noise estimate of the central crop (mrc.py:280-292) ----
-    Plane crop = b->gray;
-    crop.p += (size_t)b->crop[0] * b->gray.pitch + b->crop[2];
+    SigJob *hsj = reinterpret_cast<SigJob *>(b->hctrl + L.sigjobs);
+    SigJob *dsj = reinterpret_cast<SigJob *>(dctrl + L.sigjobs);
+    for (int i = 0; i < N; i++) {
+        hsj[i].src = b->gray.page(i) + (size_t)b->crop[0] * b->gray.pitch + b->crop[2];
+        hsj[i].pitch = b->gray.pitch;
+        hsj[i].w = b->crop[3] - b->crop[2]; hsj[i].h = b->crop[1] - b->crop[0];
+        hsj[i].as_bool = 0;
+        hsj[i].scratch = b->sig_scratch.as<char>() + (size_t)i * b->sig_stride;
+    }
+    HIP_TRY(hipMemcpyAsync(dsj, hsj, (size_t)N * sizeof(SigJob), hipMemcpyHostToDevice, s));
     double *dsig = reinterpret_cast<double *>(dctrl + L.sigma);
-    TRY(launch_estimate_sigma_batch(ctx, s, crop, b->crop[3] - b->crop[2], b->crop[1] - b->crop[0], 0, dsig,
-                                    b->sig_scratch.p, b->sig_stride, N));
+    TRY(launch_estimate_sigma_jobs(ctx, s, hsj, dsj, N, 0, dsig));
     HIP_TRY(hipMemcpyAsync(b->hctrl + L.sigma, dsig, (size_t)N * 8, hipMemcpyDeviceToHost, s));
     b->state = 2;
     return 0;
@@ -253,54 +262,75 @@ MRCHIP_EXPORT int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est) {
     return 0;
 }
 
-// mean_estimate_sigma of one of a box's bool thresholds (mrc.py:253-254); synchronous, rare
-static int box_sigma(mrchip_batch *b, const BoxInfo &bi, int inv, double *out) {
-    mrchip_ctx *ctx = b->ctx;
-    const int bw = bi.r - bi.l, bh = bi.b - bi.t;
-    const size_t need = sigma_scratch_bytes(bw, bh, 1);
-    const CtrlLayout L(b->n, (int)b->boxes.size());
-    HIP_TRY(hipStreamSynchronize(b->s));
-    TRY(b->box_sig_scratch.alloc(ctx, need));
-    Plane src;
-    src.p = (inv ? b->thB.as<uint8_t>() : b->thA.as<uint8_t>()) + 256 + bi.off + bi.phase;
-    src.pitch = bi.pitch;
-    double *dsig = reinterpret_cast<double *>(b->ctrl.as<unsigned char>() + L.box_sigma);
-    TRY(launch_estimate_sigma_batch(ctx, b->s, src, bw, bh, 1, dsig, b->box_sig_scratch.p, need, 1));
-    HIP_TRY(hipMemcpyAsync(b->hctrl + L.box_sigma, dsig, sizeof(double), hipMemcpyDeviceToHost, b->s));
-    HIP_TRY(hipStreamSynchronize(b->s));
-    *out = *reinterpret_cast<double *>(b->hctrl + L.box_sigma);
-    return 0;
-}
-
-// decisions (mrc.py:240-263, host float64 like the reference) + ordered commit (mrc.py:266)
+// decisions (mrc.py:240-263, host float64 like the reference) + ordered commit (mrc.py:266).
+// Boxes whose ratios do not settle the polarity need mean_estimate_sigma of both bool thresholds
+// (mrc.py:253-254): all of them, over the whole batch, run as ONE job list (float64 path) and
+// one synchronisation.
 static int decide_and_commit(mrchip_batch *b) {
     const int nb = (int)b->boxes.size();
     if (nb == 0) return 0;
+    mrchip_ctx *ctx = b->ctx;
+    hipStream_t s = b->s;
     const CtrlLayout L(b->n, nb);
+    unsigned char *dctrl = b->ctrl.as<unsigned char>();
     const unsigned *counts = reinterpret_cast<const unsigned *>(b->hctrl + L.counts);
-    HocrBox *hb = reinterpret_cast<HocrBox *>(b->hctrl + L.boxes);
-    HocrBox *db = reinterpret_cast<HocrBox *>(b->ctrl.as<unsigned char>() + L.boxes);
-    int maxw = 0, maxh = 0;
-    double area = 0;
+    std::vector<int> need;          // boxes on the sigma path
+    std::vector<double> ratio(nb), inv_ratio(nb);
     for (int i = 0; i < nb; i++) {
         BoxInfo &bi = b->boxes[i];
         const double size = (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
-        const double ratio = (double)counts[2 * i] / size;             // mrc.py:231-233
-        const double inv_ratio = (double)counts[2 * i + 1] / size;     // mrc.py:236-238
-        int dec = 0;
-        if (ratio < 0.3 || inv_ratio < 0.3) {                          // mrc.py:240
-            if (inv_ratio > 0.2 && ratio < 0.2) dec = 1;               // mrc.py:247-248
-            else {
-                double rs = 0, irs = 0;
-                TRY(box_sigma(b, bi, 0, &rs));                         // mrc.py:253
-                TRY(box_sigma(b, bi, 1, &irs));                        // mrc.py:254
-                if (inv_ratio < 0.3 && inv_ratio < ratio && (irs < rs || (rs < 0.1 && irs < 0.1))) dec = 2;
-                else if (ratio < 0.2) dec = 1;                         // mrc.py:258-263
-            }
+        ratio[i] = (double)counts[2 * i] / size;                       // mrc.py:231-233
+        inv_ratio[i] = (double)counts[2 * i + 1] / size;               // mrc.py:236-238
+        bi.decision = 0;
+        if (ratio[i] < 0.3 || inv_ratio[i] < 0.3) {                    // mrc.py:240
+            if (inv_ratio[i] > 0.2 && ratio[i] < 0.2) bi.decision = 1; // mrc.py:247-248
+            else need.push_back(i);
         }
-        bi.decision = dec;
+    }
+    if (!need.empty()) {
+        const int nj = (int)need.size() * 2;
+        size_t total = 0;
+        std::vector<size_t> offs(nj);
+        for (int k = 0; k < nj; k++) {
+            const BoxInfo &bi = b->boxes[need[k / 2]];
+            offs[k] = total;
+            total += sigma_scratch_bytes(bi.r - bi.l, bi.b - bi.t, 1);
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        TRY(b->box_sig_scratch.alloc(ctx, total + 256));
+        SigJob *hj = reinterpret_cast<SigJob *>(b->hctrl + L.boxsigjobs);
+        SigJob *dj = reinterpret_cast<SigJob *>(dctrl + L.boxsigjobs);
+        for (int k = 0; k < nj; k++) {
+            const BoxInfo &bi = b->boxes[need[k / 2]];
+            hj[k].src = ((k & 1) ? b->thB.as<uint8_t>() : b->thA.as<uint8_t>()) + 256 + bi.off + bi.phase;
+            hj[k].pitch = bi.pitch;
+            hj[k].w = bi.r - bi.l; hj[k].h = bi.b - bi.t;
+            hj[k].as_bool = 1;
+            hj[k].scratch = b->box_sig_scratch.as<char>() + offs[k];
+        }
+        double *dsig = reinterpret_cast<double *>(dctrl + L.box_sigma);
+        HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(SigJob), hipMemcpyHostToDevice, s));
+        TRY(launch_estimate_sigma_jobs(ctx, s, hj, dj, nj, 1, dsig));
+        HIP_TRY(hipMemcpyAsync(b->hctrl + L.box_sigma, dsig, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const double *hs = reinterpret_cast<const double *>(b->hctrl + L.box_sigma);
+        for (size_t q = 0; q < need.size(); q++) {
+            const int i = need[q];
+            const double rs = hs[2 * q], irs = hs[2 * q + 1];          // mrc.py:253-254
+            if (inv_ratio[i] < 0.3 && inv_ratio[i] < ratio[i] && (irs < rs || (rs < 0.1 && irs < 0.1)))
+                b->boxes[i].decision = 2;
+            else if (ratio[i] < 0.2)
+                b->boxes[i].decision = 1;                              // mrc.py:258-263
+        }
+    }
+    HocrBox *hb = reinterpret_cast<HocrBox *>(b->hctrl + L.boxes);
+    HocrBox *db = reinterpret_cast<HocrBox *>(dctrl + L.boxes);
+    int maxw = 0, maxh = 0;
+    double area = 0;
+    for (int i = 0; i < nb; i++) {
+        const BoxInfo &bi = b->boxes[i];
         hb[i].l = bi.l; hb[i].t = bi.t; hb[i].r = bi.r; hb[i].b = bi.b;
-        hb[i].decision = dec;
+        hb[i].decision = bi.decision;
         hb[i].th = b->thA.as<uint8_t>() + 256 + bi.off + bi.phase;
         hb[i].thi = b->thB.as<uint8_t>() + 256 + bi.off + bi.phase;
         hb[i].pitch = bi.pitch;
@@ -308,10 +338,10 @@ static int decide_and_commit(mrchip_batch *b) {
         hb[i].mpitch = b->mask.pl.pitch;
         hb[i].page_end = b->first_box[bi.page + 1];
         maxw = std::max(maxw, bi.r - bi.l); maxh = std::max(maxh, bi.b - bi.t);
-        if (dec) area += size;
+        if (bi.decision) area += (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
     }
-    HIP_TRY(hipMemcpyAsync(db, hb, (size_t)nb * sizeof(HocrBox), hipMemcpyHostToDevice, b->s));
-    return launch_hocr_commit(b->ctx, b->s, db, nb, maxw, maxh, area);
+    HIP_TRY(hipMemcpyAsync(db, hb, (size_t)nb * sizeof(HocrBox), hipMemcpyHostToDevice, s));
+    return launch_hocr_commit(ctx, s, db, nb, maxw, maxh, area);
 }
 
 MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weights, const int *radius, int denoise_fast) {

@@ -112,9 +112,12 @@ MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int
     TRY(scratch.alloc(ctx, sigma_scratch_bytes(w, h, kind)));
     TRY(res.alloc(ctx, 64));
     TRY(upload_2d(s, m.p, m.pitch, arr, stride, w, h));
-    Plane pm;
-    pm.p = m.p; pm.pitch = m.pitch;
-    TRY(launch_estimate_sigma_batch(ctx, s, pm, w, h, kind, res.as<double>(), scratch.p, 0, 1));
+    DevBuf jb;
+    TRY(jb.alloc(ctx, sizeof(SigJob)));
+    SigJob job = {m.p, m.pitch, w, h, kind, scratch.as<char>()};
+    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
+    TRY(launch_estimate_sigma_jobs(ctx, s, &job, jb.as<SigJob>(), 1, kind, res.as<double>()));
     HIP_TRY(hipMemcpyAsync(sigma, res.p, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -62,18 +62,19 @@ struct SelState {
 };
 
 template <class T>
-__global__ __launch_bounds__(256) void dwt_dd_kernel(const uint8_t *src, int pitch, size_t sstride, int w, int h,
-                                                     int as_bool, Db2<T> F, char *scratch, size_t scratch_stride,
-                                                     size_t dd_off, int w2, int h2) {
+__global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> F, size_t dd_off) {
+    const SigJob J = jobs[blockIdx.z];
+    const int w = J.w, h = J.h, pitch = J.pitch, as_bool = J.as_bool;
+    const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
     const int m = blockIdx.x * 256 + threadIdx.x;   // column of dd
     const int k = blockIdx.y;                       // row of dd
-    if (blockIdx.x == 0 && blockIdx.y == 0) {       // reset this page's selection state
-        unsigned *z = reinterpret_cast<unsigned *>(scratch + (size_t)blockIdx.z * scratch_stride);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {       // reset this job's selection state
+        unsigned *z = reinterpret_cast<unsigned *>(J.scratch);
         for (int i = threadIdx.x; i < (int)(sizeof(SelState) / 4); i += 256) z[i] = 0;
     }
-    if (m >= w2) return;
-    src += (size_t)blockIdx.z * sstride;
-    T *dd = reinterpret_cast<T *>(scratch + (size_t)blockIdx.z * scratch_stride + dd_off);
+    if (m >= w2 || k >= h2) return;
+    const uint8_t *src = J.src;
+    T *dd = reinterpret_cast<T *>(J.scratch + dd_off);
     auto px = [&](int yy, int xx) -> T {
         unsigned v = src[(size_t)yy * pitch + xx];
         return as_bool ? (T)(v ? 1 : 0) : (T)v;
@@ -103,11 +104,12 @@ template <> struct Key<double> {
 // histogram of the digit at `shift` (width `bits`) among the non-zero |dd| whose higher
 // bits equal prefix[r]
 template <class T>
-__global__ __launch_bounds__(256) void sel_hist_kernel(char *scratch, size_t scratch_stride, size_t dd_off, size_t n,
-                                                       int shift, int bits, int first) {
+__global__ __launch_bounds__(256) void sel_hist_kernel(const SigJob *jobs, size_t dd_off, int shift, int bits, int first) {
     using U = typename Key<T>::U;
-    SelState *st = reinterpret_cast<SelState *>(scratch + (size_t)blockIdx.y * scratch_stride);
-    const T *dd = reinterpret_cast<const T *>(scratch + (size_t)blockIdx.y * scratch_stride + dd_off);
+    const SigJob J = jobs[blockIdx.y];
+    SelState *st = reinterpret_cast<SelState *>(J.scratch);
+    const T *dd = reinterpret_cast<const T *>(J.scratch + dd_off);
+    const size_t n = (size_t)((J.w + 3) / 2) * ((J.h + 3) / 2);
     __shared__ unsigned lh[2][NBIN];
     for (int i = threadIdx.x; i < 2 * NBIN; i += 256) (&lh[0][0])[i] = 0;
     __syncthreads();
@@ -132,10 +134,9 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(char *scratch, size_t scr
 // one wave: locate the bins of both ranks, extend the prefixes, clear the histograms;
 // on the last digit produce sigma.  Lane l owns bins [l*per, (l+1)*per).
 template <class T>
-__global__ __launch_bounds__(64) void sel_scan_kernel(char *scratch, size_t scratch_stride, int bits, int first, int last,
-                                                      double *d_sigma) {
+__global__ __launch_bounds__(64) void sel_scan_kernel(const SigJob *jobs, int bits, int first, int last, double *d_sigma) {
     using U = typename Key<T>::U;
-    SelState *st = reinterpret_cast<SelState *>(scratch + (size_t)blockIdx.x * scratch_stride);
+    SelState *st = reinterpret_cast<SelState *>(jobs[blockIdx.x].scratch);
     const int lane = threadIdx.x;
     const int nb = 1 << bits;
     const int per = (nb + 63) / 64;
@@ -204,18 +205,25 @@ __global__ __launch_bounds__(64) void sel_scan_kernel(char *scratch, size_t scra
 static size_t dd_offset() { return (sizeof(SelState) + 255) & ~(size_t)255; }
 
 template <class T>
-static int run_sigma(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int as_bool, char *scratch,
-                     size_t scratch_stride, double *d_sigma, int npages, double alg) {
+static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
+                     double *d_sigma) {
     static const double HI[4] = {-0.48296291314453416, 0.8365163037378079, -0.2241438680420134,
                                  -0.12940952255126037};
     Db2<T> F;
     for (int i = 0; i < 4; i++) F.f[i] = (T)HI[i];
-    const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
+    int maxw2 = 0, maxh2 = 0;
+    double alg = 0;
+    size_t maxn = 0;
+    for (int i = 0; i < njobs; i++) {
+        const int w2 = (h_jobs[i].w + 3) / 2, h2 = (h_jobs[i].h + 3) / 2;
+        maxw2 = std::max(maxw2, w2); maxh2 = std::max(maxh2, h2);
+        maxn = std::max(maxn, (size_t)w2 * h2);
+        alg += (double)h_jobs[i].w * h_jobs[i].h;
+    }
     LAUNCH(ctx, s, sizeof(T) == 4 ? "dwt_dd_f32" : "dwt_dd_f64", alg,
-           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(w2, 256), h2, npages), dim3(256), 0, s, src.p, src.pitch,
-                              src.stride, w, h, as_bool, F, scratch, scratch_stride, dd_offset(), w2, h2));
-    const size_t n = (size_t)w2 * h2;
-    const int blocks = (int)std::min<size_t>(npages > 8 ? 64 : 512, (n + 255) / 256);
+           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(maxw2, 256), maxh2, njobs), dim3(256), 0, s, d_jobs, F,
+                              dd_offset()));
+    const int blocks = (int)std::min<size_t>(njobs > 8 ? 64 : 512, (maxn + 255) / 256);
     int shift = Key<T>::BITS;
     int first = 1;
     while (shift > 0) {
@@ -223,11 +231,10 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, in
         shift -= bits;
         const int last = shift == 0;
         LAUNCH(ctx, s, "median_hist", 0.0,
-               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks, npages), dim3(256), 0, s, scratch, scratch_stride,
-                                  dd_offset(), n, shift, bits, first));
+               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks, njobs), dim3(256), 0, s, d_jobs, dd_offset(), shift,
+                                  bits, first));
         LAUNCH(ctx, s, "median_scan", 0.0,
-               hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(npages), dim3(64), 0, s, scratch, scratch_stride, bits, first,
-                                  last, d_sigma));
+               hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(njobs), dim3(64), 0, s, d_jobs, bits, first, last, d_sigma));
         first = 0;
     }
     return 0;
@@ -238,12 +245,14 @@ size_t sigma_scratch_bytes(int w, int h, int kind) {
     return ((dd_offset() + n * (kind ? sizeof(double) : sizeof(float)) + 255) & ~(size_t)255);
 }
 
-int launch_estimate_sigma_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int kind, double *d_sigma,
-                                void *scratch, size_t scratch_stride, int npages) {
-    if (w <= 0 || h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
-    char *sc = reinterpret_cast<char *>(scratch);
-    if (kind == 0) return run_sigma<float>(ctx, s, src, w, h, 0, sc, scratch_stride, d_sigma, npages, 1.0 * w * h * npages);
-    return run_sigma<double>(ctx, s, src, w, h, 1, sc, scratch_stride, d_sigma, npages, 1.0 * w * h * npages);
+// h_jobs / d_jobs: the same njobs records on host and device; job i's result lands in d_sigma[i]
+int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
+                               int kind, double *d_sigma) {
+    if (njobs <= 0) return 0;
+    for (int i = 0; i < njobs; i++)
+        if (h_jobs[i].w <= 0 || h_jobs[i].h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
+    if (kind == 0) return run_sigma<float>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);
+    return run_sigma<double>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);
 }
 
 }  // namespace mrchip

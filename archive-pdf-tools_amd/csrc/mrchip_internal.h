@@ -207,9 +207,15 @@ size_t ThumbPlan_table_bytes(const ThumbPlan &p);
 int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
                           const int32_t *d_tables, Plane scratch1, Plane scratch2, int npages);
 size_t sigma_scratch_bytes(int w, int h, int kind);
-// page i: crop at src.page(i), scratch at scratch + i*scratch_stride, result in d_sigma[i]
-int launch_estimate_sigma_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, int w, int h, int kind, double *d_sigma,
-                                void *scratch, size_t scratch_stride, int npages);
+// one noise estimate = one job (a page's central crop, or one bool threshold of an hOCR box)
+struct SigJob {
+    const uint8_t *src; int pitch;
+    int w, h;
+    int as_bool;
+    char *scratch;      // sigma_scratch_bytes(w, h, kind) bytes, 256-byte aligned
+};
+int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
+                               int kind, double *d_sigma);
 constexpr int GMAXR = 60;
 struct GaussW { double w[2 * GMAXR + 1]; int radius; int pad_; };
 // d_weights: npages GaussW records (radius 0 = identity); tmp: page i at tmp + i*tstride floats
