@@ -337,6 +337,11 @@ static int decide_and_commit(mrchip_batch *b) {
         hb[i].mask = b->mask.pl.page(bi.page);
         hb[i].mpitch = b->mask.pl.pitch;
         hb[i].page_end = b->first_box[bi.page + 1];
+        hb[i].overlapped = 0;
+        for (int j = i + 1; j < hb[i].page_end; j++) {
+            const BoxInfo &bj = b->boxes[j];
+            if (bj.decision && bj.l < bi.r && bi.l < bj.r && bj.t < bi.b && bi.t < bj.b) { hb[i].overlapped = 1; break; }
+        }
         maxw = std::max(maxw, bi.r - bi.l); maxh = std::max(maxh, bi.b - bi.t);
         if (bi.decision) area += (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
     }
@@ -434,7 +439,8 @@ static int prepare_thumb(mrchip_batch *b, int Lr, double downsample, int *too_sm
             HIP_TRY(hipMemcpy(d, p.bh_.data(), p.bh_.size() * 4, hipMemcpyHostToDevice)); d += p.bh_.size();
             HIP_TRY(hipMemcpy(d, p.kh_.data(), p.kh_.size() * 4, hipMemcpyHostToDevice)); d += p.kh_.size();
             HIP_TRY(hipMemcpy(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice)); d += p.bv_.size();
-            HIP_TRY(hipMemcpy(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice)); d += p.kv_.size();
+            if (!p.khT_.empty()) HIP_TRY(hipMemcpy(d, p.khT_.data(), p.khT_.size() * 4, hipMemcpyHostToDevice));
         }
     }
     if (p.changed) { b->layer_w[Lr] = p.ow; b->layer_h[Lr] = p.oh; b->layer_small[Lr] = 1; }

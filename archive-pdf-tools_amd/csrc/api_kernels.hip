@@ -197,7 +197,8 @@ MRCHIP_EXPORT int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, in
     HIP_TRY(hipMemcpyAsync(d, p.bh_.data(), p.bh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bh_.size();
     HIP_TRY(hipMemcpyAsync(d, p.kh_.data(), p.kh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.kh_.size();
     HIP_TRY(hipMemcpyAsync(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bv_.size();
-    HIP_TRY(hipMemcpyAsync(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.kv_.size();
+    if (!p.khT_.empty()) HIP_TRY(hipMemcpyAsync(d, p.khT_.data(), p.khT_.size() * 4, hipMemcpyHostToDevice, s));
     TRY(upload_2d(s, src.p, src.pitch, in, w * c, w * c, h));
     Plane psrc, pdst, p1, p2;
     psrc.p = src.p; psrc.pitch = src.pitch;

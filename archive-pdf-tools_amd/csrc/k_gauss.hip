@@ -23,23 +23,33 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
+// vertical pass: one lane per 4 adjacent pixels (aligned dword loads, float4 store)
 __global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int spitch, size_t sstride, float *tmp,
                                                       int tpitch, size_t tstride, int w, int h, const GaussW *Gs) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w) return;
     src += (size_t)blockIdx.z * sstride;
     tmp += (size_t)blockIdx.z * tstride;
     const GaussW &G = Gs[blockIdx.z];
     const int r = G.radius;
-    double acc = __dmul_rn((double)src[(size_t)y * spitch + x], G.w[r]);
+    auto ld4 = [&](int yy) { return *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x); };
+    const unsigned c = ld4(y);
+    const double wc = G.w[r];
+    double a0 = __dmul_rn((double)(c & 0xffu), wc), a1 = __dmul_rn((double)((c >> 8) & 0xffu), wc);
+    double a2 = __dmul_rn((double)((c >> 16) & 0xffu), wc), a3 = __dmul_rn((double)(c >> 24), wc);
     for (int j = -r; j < 0; j++) {
-        double a = (double)src[(size_t)reflect_idx(y + j, h) * spitch + x];
-        double b = (double)src[(size_t)reflect_idx(y - j, h) * spitch + x];
-        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(a, b), G.w[r + j]));
+        const unsigned p = ld4(reflect_idx(y + j, h)), q = ld4(reflect_idx(y - j, h));
+        const double wj = G.w[r + j];
+        a0 = __dadd_rn(a0, __dmul_rn(__dadd_rn((double)(p & 0xffu), (double)(q & 0xffu)), wj));
+        a1 = __dadd_rn(a1, __dmul_rn(__dadd_rn((double)((p >> 8) & 0xffu), (double)((q >> 8) & 0xffu)), wj));
+        a2 = __dadd_rn(a2, __dmul_rn(__dadd_rn((double)((p >> 16) & 0xffu), (double)((q >> 16) & 0xffu)), wj));
+        a3 = __dadd_rn(a3, __dmul_rn(__dadd_rn((double)(p >> 24), (double)(q >> 24)), wj));
     }
-    tmp[(size_t)y * tpitch + x] = (float)acc;
+    // columns >= w of the last dword are written too: they live in the scratch row's padding
+    *reinterpret_cast<float4 *>(tmp + (size_t)y * tpitch + x) = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
 
+// horizontal pass: one lane per output (consecutive lanes read consecutive floats)
 __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpitch, size_t tstride, uint8_t *dst,
                                                       int dpitch, size_t dstride, int w, int h, const GaussW *Gs) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -50,10 +60,13 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
     const int r = G.radius;
     const float *row = tmp + (size_t)y * tpitch;
     double acc = __dmul_rn((double)row[x], G.w[r]);
-    for (int j = -r; j < 0; j++) {
-        double a = (double)row[reflect_idx(x + j, w)];
-        double b = (double)row[reflect_idx(x - j, w)];
-        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(a, b), G.w[r + j]));
+    if (x - r >= 0 && x + r < w) {
+        for (int j = -r; j < 0; j++)
+            acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[x + j], (double)row[x - j]), G.w[r + j]));
+    } else {
+        for (int j = -r; j < 0; j++)
+            acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[reflect_idx(x + j, w)], (double)row[reflect_idx(x - j, w)]),
+                                           G.w[r + j]));
     }
     dst[(size_t)y * dpitch + x] = (uint8_t)(float)acc;      // float32 result, astype(uint8) truncation
 }
@@ -85,9 +98,10 @@ int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
 // mrc.py:309) ride along in the same launch.
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
                           float *tmp, int tpitch, size_t tstride, int npages) {
+    dim3 grid_v(cdiv(cdiv(w, 4), 256), h, npages);
     dim3 grid(cdiv(w, 256), h, npages);
     LAUNCH(ctx, s, "gauss_v", 5.0 * w * h * npages,
-           hipLaunchKernelGGL(gauss_v_kernel, grid, dim3(256), 0, s, src.p, src.pitch, src.stride, tmp, tpitch, tstride, w, h,
+           hipLaunchKernelGGL(gauss_v_kernel, grid_v, dim3(256), 0, s, src.p, src.pitch, src.stride, tmp, tpitch, tstride, w, h,
                               d_weights));
     LAUNCH(ctx, s, "gauss_h", 5.0 * w * h * npages,
            hipLaunchKernelGGL(gauss_h_kernel, grid, dim3(256), 0, s, tmp, tpitch, tstride, dst.p, dst.pitch, dst.stride, w, h,

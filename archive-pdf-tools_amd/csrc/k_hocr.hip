@@ -9,27 +9,50 @@ namespace mrchip {
 __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes) {
     const int b = blockIdx.z;
     const HocrBox B = boxes[b];
+    if (B.decision == 0) return;
     uint8_t *mask = B.mask;
     const int mpitch = B.mpitch, nb = B.page_end;
-    if (B.decision == 0) return;
     const int bw = B.r - B.l, bh = B.b - B.t;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= bw) return;
+    // one lane per 4 pixels, dword-aligned in the MASK's coordinates (the box scratch has the
+    // same column phase mod 16, so its dwords line up too)
+    const int xa = (B.l & ~3) + (blockIdx.x * 256 + threadIdx.x) * 4;     // absolute column of the dword
+    if (xa >= B.r) return;
     const uint8_t *th = B.decision == 1 ? B.th : B.thi;
+    // later boxes with a decision that intersect this column group (wave-uniform scalar loop)
     for (int y = blockIdx.y; y < bh; y += gridDim.y) {
-        const int px = B.l + x, py = B.t + y;
-        bool covered = false;
-        for (int j = b + 1; j < nb && !covered; j++) {
-            const HocrBox &L = boxes[j];
-            covered = L.decision != 0 && px >= L.l && px < L.r && py >= L.t && py < L.b;
+        const int py = B.t + y;
+        unsigned keep = 0;                       // byte mask of pixels this box owns
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int px = xa + i;
+            if (px >= B.l && px < B.r) keep |= 0xffu << (8 * i);
         }
-        if (!covered) mask[(size_t)py * mpitch + px] = th[(size_t)y * B.pitch + x];
+        if (B.overlapped) {                      // rare: some later box with a decision intersects this one
+            for (int j = b + 1; j < nb; j++) {
+                const HocrBox &L = boxes[j];
+                if (L.decision == 0 || py < L.t || py >= L.b) continue;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int px = xa + i;
+                    if (px >= L.l && px < L.r) keep &= ~(0xffu << (8 * i));
+                }
+            }
+        }
+        if (!keep) continue;
+        const unsigned v = *reinterpret_cast<const unsigned *>(th + (ptrdiff_t)y * B.pitch + (xa - B.l));
+        uint8_t *mp = mask + (size_t)py * mpitch + xa;
+        if (keep == 0xffffffffu) *reinterpret_cast<unsigned *>(mp) = v;
+        else {      // partial dword: byte stores, so that a neighbouring box's bytes are never rewritten
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if ((keep >> (8 * i)) & 0xffu) mp[i] = (uint8_t)(v >> (8 * i));
+        }
     }
 }
 
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area) {
     if (nb <= 0) return 0;
-    dim3 grid(cdiv(maxw, 256), std::min(maxh, 64), nb);
+    dim3 grid(cdiv(cdiv(maxw + 3, 4), 256), std::min(maxh, 64), nb);
     LAUNCH(ctx, s, "hocr_commit", 2.0 * area,
            hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes));
     return 0;

@@ -31,23 +31,24 @@ struct RowRegs {
     unsigned px[P * C / 4];     // P*C image bytes
 };
 
+typedef const unsigned __attribute__((address_space(1))) *gc_u32p;     // global (not flat) loads
+typedef unsigned __attribute__((address_space(1))) *g_u32p;
+
+// Unconditional loads from a row clamped into the image: no exec-masked load blocks (hipcc puts an
+// `s_waitcnt vmcnt(0)` behind every predicated load, one exposed memory round trip each).  Whether
+// the row / the columns count is decided where the bytes are USED (wave-uniform row tests, column
+// byte masks).  Columns >= w read the row's padding (or the next row), which the masks zero.
 template <int C, int P>
 __device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
-                                                       int y, int x0, bool ok) {
+                                                       int y, int h, int x0) {
     RowRegs<C, P> r;
-    if (ok) {
-        const unsigned *pm = reinterpret_cast<const unsigned *>(mask + (size_t)y * mpitch + x0);
-        const unsigned *pi = reinterpret_cast<const unsigned *>(img + (size_t)y * ipitch + (size_t)x0 * C);
+    const int yc = min(max(y, 0), h - 1);
+    gc_u32p pm = (gc_u32p)(mask + (size_t)yc * mpitch + x0);
+    gc_u32p pi = (gc_u32p)(img + (size_t)yc * ipitch + (size_t)x0 * C);
 #pragma unroll
-        for (int i = 0; i < P / 4; i++) r.m[i] = pm[i];
+    for (int i = 0; i < P / 4; i++) r.m[i] = pm[i];
 #pragma unroll
-        for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < P / 4; i++) r.m[i] = 0;
-#pragma unroll
-        for (int i = 0; i < P * C / 4; i++) r.px[i] = 0;
-    }
+    for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
     return r;
 }
 
@@ -58,7 +59,8 @@ __device__ __forceinline__ unsigned byte_at(const unsigned (&v)[N], int j) { ret
 
 // val / cnt for 0 <= val <= 255*cnt and cnt <= 5120 (n <= 32): the quotient is <= 255 and its
 // fractional part is a multiple of 1/cnt, so (val + 0.5) * rcp(cnt) truncates to it exactly
-// (val < 2^23 is exact in fp32; margin 0.5/cnt >= 9.7e-5 against an error below 255 * 2^-22 = 6.1e-5).
+// (val < 2^23 is exact in fp32; margin 0.5/cnt >= 9.7e-5 against an error below 255 * 1.5 * 2^-23 = 4.6e-5
+// with the 1-ulp v_rcp_f32).
 __device__ __forceinline__ unsigned div_small(int val, float rc) { return (unsigned)(((float)val + 0.5f) * rc); }
 
 template <int C, int P, int MAXT>
@@ -100,27 +102,69 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
 #pragma unroll
     for (int i = 0; i < P * C / 4; i++) prev[i] = 0;
 
+    // byte masks of the valid columns: colm (one byte per column) and pxm (C bytes per column)
+    unsigned colm[P / 4], pxm[P * C / 4];
+#pragma unroll
+    for (int q = 0; q < P / 4; q++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if ((colok >> (4 * q + b)) & 1u) m |= 0xffu << (8 * b);
+        colm[q] = m;
+    }
+#pragma unroll
+    for (int q = 0; q < P * C / 4; q++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if ((colok >> ((4 * q + b) / C)) & 1u) m |= 0xffu << (8 * b);
+        pxm[q] = m;
+    }
+    // 0xFF per selected ("on") column: nonzero mask byte, optionally inverted, inside the image
+    auto on_bytes = [&](const unsigned (&m)[P / 4], unsigned (&on)[P / 4]) {
+#pragma unroll
+        for (int q = 0; q < P / 4; q++) {
+            unsigned t = (((m[q] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m[q]) & 0x80808080u;   // 0x80 per nonzero byte
+            t = (t - (t >> 7)) | t;                                                       // -> 0xFF
+            on[q] = (invb ? ~t : t) & colm[q];
+        }
+    };
+    // expand one mask byte per column to C bytes per column (interleaved pixel layout)
+    auto expand_px = [&](const unsigned (&on)[P / 4], unsigned (&e)[P * C / 4]) {
+        if constexpr (C == 1) {
+#pragma unroll
+            for (int q = 0; q < P / 4; q++) e[q] = on[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < P / 4; q++) {
+                // bytes M0 M1 M2 M3 -> [M0 M0 M0 M1] [M1 M1 M2 M2] [M2 M3 M3 M3]
+                e[3 * q + 0] = __builtin_amdgcn_perm(0u, on[q], 0x01000000u);
+                e[3 * q + 1] = __builtin_amdgcn_perm(0u, on[q], 0x02020101u);
+                e[3 * q + 2] = __builtin_amdgcn_perm(0u, on[q], 0x03030302u);
+            }
+        }
+    };
     auto fir_apply = [&](const RowRegs<C, P> &r, int sign) {
+        unsigned on[P / 4], e[P * C / 4];
+        on_bytes(r.m, on);
+        expand_px(on, e);
 #pragma unroll
         for (int i = 0; i < P; i++) {
-            const unsigned mb = byte_at(r.m, i);
-            const bool on = ((((mb != 0) ? 1u : 0u) ^ invb) != 0) && ((colok >> i) & 1u);
-            if (on) {
-                firc[i] += sign;
+            firc[i] += sign * (int)(byte_at(on, i) & 1u);
 #pragma unroll
-                for (int c = 0; c < C; c++) fir[i][c] += sign * (int)byte_at(r.px, i * C + c);
+            for (int c = 0; c < C; c++) {
+                const int j = i * C + c;
+                fir[i][c] += sign * (int)(((r.px[j >> 2] & e[j >> 2]) >> (8 * (j & 3))) & 0xffu);
             }
         }
     };
 
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, x0, act);
+        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0);
         fir_apply(r, +1);
     }
-    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, x0, act && (n - 1 < h) && n >= 1);
-    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, x0, false);
-    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, x0, act);
+    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, h, x0);
+    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
+    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
     unsigned o_leave[P * C / 4];
 #pragma unroll
     for (int i = 0; i < P * C / 4; i++) o_leave[i] = 0;
@@ -128,34 +172,32 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
     for (int y = 0; y < h; y++) {
         // ---- issue next row's loads first (independent of the serial chain) ----
         const int yn = y + 1;
-        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, x0, act && (yn + n - 1 < h));
-        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, x0, act && (yn - n - 1 >= 0));
-        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, x0, act && (yn < h));
+        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, h, x0);
+        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, h, x0);
+        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, h, x0);
         unsigned n_oleave[P * C / 4];
         {
-            const bool ok = act && (yn - n - 1 >= 0);
-            const unsigned *p = reinterpret_cast<const unsigned *>(out + (size_t)max(yn - n - 1, 0) * opitch + (size_t)x0 * C);
+            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)x0 * C);
 #pragma unroll
-            for (int i = 0; i < P * C / 4; i++) n_oleave[i] = ok ? p[i] : 0u;
+            for (int i = 0; i < P * C / 4; i++) n_oleave[i] = p[i];
         }
 
         // ---- vertical running sums for row y ----
         if (y + n - 1 < h && n >= 1) fir_apply(r_enter, +1);      // row y+n-1 enters (ye = min(h, y+n))
         if (y - n - 1 >= 0 && n >= 1) fir_apply(r_leave, -1);     // row y-n-1 leaves (ys = max(0, y-n))
-        if (y >= 1 && n >= 1) {
+        if (y >= 1 && n >= 1) {      // prev / o_leave carry zeros in the bytes of columns >= w
 #pragma unroll
             for (int i = 0; i < P; i++)
-                if ((colok >> i) & 1u) {
 #pragma unroll
-                    for (int c = 0; c < C; c++) iir[i][c] += (int)byte_at(prev, i * C + c);
-                }
+                for (int c = 0; c < C; c++) iir[i][c] += (int)byte_at(prev, i * C + c);
         }
         if (y - n - 1 >= 0 && n >= 1) {
 #pragma unroll
             for (int i = 0; i < P; i++)
-                if ((colok >> i) & 1u) {
 #pragma unroll
-                    for (int c = 0; c < C; c++) iir[i][c] -= (int)byte_at(o_leave, i * C + c);
+                for (int c = 0; c < C; c++) {
+                    const int j = i * C + c;
+                    iir[i][c] -= (int)(((o_leave[j >> 2] & pxm[j >> 2]) >> (8 * (j & 3))) & 0xffu);
                 }
         }
         const int ys = max(0, y - n);
@@ -174,7 +216,7 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
                 iirA[e] = (unsigned)iir[i][0];
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- horizontal sliding windows over the LDS rows ----
         int fs[C], is[C], fc = 0;
@@ -205,20 +247,15 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
         for (int j = -n; j < n; j++) add_fir(x0 + j, +1);
         for (int j = -n; j < 0; j++) add_iir(x0 + j, +1);
 
-        unsigned resb[P * C];
+        unsigned qb[P * C];
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int x = x0 + i;
             const int xs = max(0, x - n);
             const int cnt = fc + (y - ys) * (x - xs);
-            const unsigned mb = byte_at(r_cur.m, i);
-            const bool masked = (((mb != 0) ? 1u : 0u) ^ invb) != 0;
-            const float rc = __frcp_rn((float)max(cnt, 1));
+            const float rc = __builtin_amdgcn_rcpf((float)max(cnt, 1));   // 1 ulp: inside div_small's margin
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                unsigned q = cnt > 0 ? div_small(fs[c] + is[c], rc) : 0u;
-                resb[i * C + c] = masked ? byte_at(r_cur.px, i * C + c) : q;   // masked pixels keep the image value
-            }
+            for (int c = 0; c < C; c++) qb[i * C + c] = cnt > 0 ? div_small(fs[c] + is[c], rc) : 0u;
             if (i + 1 < P) {      // slide to pixel x+1
                 add_fir(x + n, +1);
                 add_fir(x - n, -1);
@@ -226,31 +263,303 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
                 add_iir(x - n, -1);
             }
         }
+        // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient
         unsigned res[P * C / 4];
+        {
+            unsigned on[P / 4], e[P * C / 4];
+            on_bytes(r_cur.m, on);
+            expand_px(on, e);
 #pragma unroll
-        for (int q = 0; q < P * C / 4; q++)
-            res[q] = (resb[4 * q] & 0xffu) | ((resb[4 * q + 1] & 0xffu) << 8) | ((resb[4 * q + 2] & 0xffu) << 16) |
-                     (resb[4 * q + 3] << 24);
+            for (int q = 0; q < P * C / 4; q++) {
+                const unsigned qq = (qb[4 * q] & 0xffu) | ((qb[4 * q + 1] & 0xffu) << 8) | ((qb[4 * q + 2] & 0xffu) << 16) |
+                                    (qb[4 * q + 3] << 24);
+                res[q] = ((r_cur.px[q] & e[q]) | (qq & ~e[q])) & pxm[q];
+            }
+        }
         // ---- store the row (whole dwords inside the image, bytes at the right edge) ----
         if (act) {
             uint8_t *o = out + (size_t)y * opitch + (size_t)x0 * C;
             if (x0 + P <= w) {
 #pragma unroll
-                for (int q = 0; q < P * C / 4; q++) reinterpret_cast<unsigned *>(o)[q] = res[q];
+                for (int q = 0; q < P * C / 4; q++) ((g_u32p)o)[q] = res[q];
             } else {
                 const int nbytes = (w - x0) * C;
 #pragma unroll
                 for (int j = 0; j < P * C; j++)
-                    if (j < nbytes) o[j] = (uint8_t)resb[j];
+                    if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
             }
         }
 #pragma unroll
         for (int q = 0; q < P * C / 4; q++) prev[q] = res[q];
-        __syncthreads();       // everyone is done reading the LDS rows
+        lds_barrier();         // everyone is done reading the LDS rows
 
         r_enter = n_enter; r_leave = n_leave; r_cur = n_cur;
 #pragma unroll
         for (int q = 0; q < P * C / 4; q++) o_leave[q] = n_oleave[q];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Packed variant (the one the reference's two call sites use: n=3 and n=10).
+// Per column the running sums live in the registers in the very format of the LDS rows:
+//   RGB : FIR entry {fr | fg<<16, fb | cnt<<16}, IIR entry {ir | ig<<16, ib}      (2 dwords each)
+//   gray: FIR entry {f | cnt<<16},               IIR entry {i}                    (1 dword each)
+// 16-bit lanes never overflow: a column sum is <= 2n*255, a horizontal window of NH halves is
+// <= (2n/NH)*2n*255 <= 65535 for n <= 8 (NH=1) / n <= 11 (NH=2), the IIR window is <= n*n*255.
+// So every vertical update, every horizontal slide is a plain 32-bit add/sub on packed pairs
+// (lane-wise non-negative results: add first, subtract what was added before), pixel bytes are
+// routed into the lanes with v_perm_b32, and the publish step is a straight ds_write_b64.
+template <int C, int NH, int MAXT>
+__global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
+    constexpr int P = 4;
+    constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
+    constexpr int ND = P * C / 4;                 // dwords of pixel bytes per thread-row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const OptJob J = jobs[blockIdx.x];
+    const uint8_t *__restrict__ mask = J.mask;
+    const uint8_t *__restrict__ img = J.img;
+    uint8_t *out = J.out;
+    const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h, n = J.n;
+    const unsigned invm = J.invert ? 0xffffffffu : 0u;
+
+    const int npad = n;
+    const int T = blockDim.x;
+    const int t = threadIdx.x;
+    const int x0 = t * P;
+    const int nent = T * P + 2 * npad;
+    const int nelem = nent + nent / P + 1;
+    unsigned *firA = reinterpret_cast<unsigned *>(smem);
+    unsigned *iirA = firA + (size_t)nelem * EW;
+    for (int i = t; i < 2 * nelem * EW; i += T) firA[i] = 0;
+    __syncthreads();
+    // column c -> dword index of its entry (one pad entry per 4 columns: conflict-free lane stride)
+    auto eidx = [&](int col) { const int e = col + npad; return (e + (e >> 2)) * EW; };
+
+    const bool act = x0 < w;
+    unsigned colm = 0, pxm[ND];                   // 0xFF per valid column / per valid pixel byte
+#pragma unroll
+    for (int b = 0; b < 4; b++) if (x0 + b < w) colm |= 0xffu << (8 * b);
+#pragma unroll
+    for (int q = 0; q < ND; q++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (x0 + (4 * q + b) / C < w) m |= 0xffu << (8 * b);
+        pxm[q] = m;
+    }
+
+    struct Ent { unsigned d[EW]; };
+    auto eadd = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] += b.d[k];
+    };
+    auto esub = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] -= b.d[k];
+    };
+    auto lds_ld = [&](const unsigned *A, int col) {
+        Ent e;
+        const unsigned *p = A + eidx(col);
+        if constexpr (EW == 2) { uint2 v = *reinterpret_cast<const uint2 *>(p); e.d[0] = v.x; e.d[1] = v.y; }
+        else e.d[0] = p[0];
+        return e;
+    };
+
+    // 0xFF per selected column of a mask dword (nonzero byte, optional inversion, inside the image)
+    auto on_bytes = [&](unsigned m) {
+        unsigned tt = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;
+        tt = (tt - (tt >> 7)) | tt;
+        return (tt ^ invm) & colm;
+    };
+    // FIR entries of the 4 columns of a row: masked pixel bytes + selection bit
+    auto fir_entries = [&](const RowRegs<C, P> &r, Ent (&e)[P]) {
+        const unsigned on = on_bytes(r.m[0]);
+        const unsigned on01 = on & 0x01010101u;
+        if constexpr (C == 3) {
+            const unsigned d0 = r.px[0] & __builtin_amdgcn_perm(0u, on, 0x01000000u);   // [M0 M0 M0 M1]
+            const unsigned d1 = r.px[1] & __builtin_amdgcn_perm(0u, on, 0x02020101u);   // [M1 M1 M2 M2]
+            const unsigned d2 = r.px[2] & __builtin_amdgcn_perm(0u, on, 0x03030302u);   // [M2 M3 M3 M3]
+            e[0].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(on01, d0, 0x0c040c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(on01, d1, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(d2, d1, 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c060c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(d2, d2, 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c070c03u);
+        } else {
+            const unsigned d0 = r.px[0] & on;
+            e[0].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c040c00u);
+            e[1].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c060c02u);
+            e[3].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c070c03u);
+        }
+    };
+    // IIR entries of the 4 columns of an output row (bytes of columns >= w must be zero)
+    auto iir_entries = [&](const unsigned (&o)[ND], Ent (&e)[P]) {
+        if constexpr (C == 3) {
+            e[0].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(0u, o[0], 0x0c0c0c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(0u, o[1], 0x0c0c0c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(o[2], o[1], 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(o[2], o[2], 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c03u);
+        } else {
+            e[0].d[0] = o[0] & 0xffu; e[1].d[0] = (o[0] >> 8) & 0xffu; e[2].d[0] = (o[0] >> 16) & 0xffu; e[3].d[0] = o[0] >> 24;
+        }
+    };
+
+    Ent firE[P], iirE[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int k = 0; k < EW; k++) { firE[i].d[k] = 0; iirE[i].d[k] = 0; }
+    unsigned prev[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++) prev[q] = 0;
+
+    auto fir_apply = [&](const RowRegs<C, P> &r, bool plus) {
+        Ent e[P];
+        fir_entries(r, e);
+#pragma unroll
+        for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
+    };
+
+    // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
+    for (int yy = 0; yy < min(h, n - 1); yy++) {
+        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0);
+        fir_apply(r, true);
+    }
+    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, h, x0);
+    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
+    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
+    unsigned o_leave[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++) o_leave[q] = 0;
+
+    for (int y = 0; y < h; y++) {
+        // ---- next row's loads first: independent of the serial chain ----
+        const int yn = y + 1;
+        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, h, x0);
+        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, h, x0);
+        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, h, x0);
+        unsigned n_oleave[ND];
+        {
+            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)x0 * C);
+#pragma unroll
+            for (int q = 0; q < ND; q++) n_oleave[q] = p[q];
+        }
+
+        // ---- vertical running sums for row y (wave-uniform row tests) ----
+        if (y + n - 1 < h && n >= 1) fir_apply(r_enter, true);        // ye = min(h, y+n)
+        if (y - n - 1 >= 0 && n >= 1) fir_apply(r_leave, false);      // ys = max(0, y-n)
+        if (y >= 1 && n >= 1) {
+            Ent e[P];
+            iir_entries(prev, e);
+#pragma unroll
+            for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+        }
+        if (y - n - 1 >= 0 && n >= 1) {
+            unsigned ol[ND];
+#pragma unroll
+            for (int q = 0; q < ND; q++) ol[q] = o_leave[q] & pxm[q];
+            Ent e[P];
+            iir_entries(ol, e);
+#pragma unroll
+            for (int i = 0; i < P; i++) esub(iirE[i], e[i]);
+        }
+        const int ys = max(0, y - n);
+
+        // ---- publish: the registers already hold the LDS entry format ----
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int e = eidx(x0 + i);
+            if constexpr (EW == 2) {
+                *reinterpret_cast<uint2 *>(firA + e) = make_uint2(firE[i].d[0], firE[i].d[1]);
+                *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(iirE[i].d[0], iirE[i].d[1]);
+            } else {
+                firA[e] = firE[i].d[0];
+                iirA[e] = iirE[i].d[0];
+            }
+        }
+        lds_barrier();
+
+        // ---- horizontal windows of pixel x0: FIR [x0-n, x0+n) as NH packed halves, IIR [x0-n, x0) ----
+        Ent aL, aR, aI;
+#pragma unroll
+        for (int k = 0; k < EW; k++) { aL.d[k] = 0; aR.d[k] = 0; aI.d[k] = 0; }
+        for (int j = -n; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
+        for (int j = 0; j < n; j++) {
+            if constexpr (NH == 2) eadd(aR, lds_ld(firA, x0 + j)); else eadd(aL, lds_ld(firA, x0 + j));
+        }
+
+        unsigned qd[ND];
+#pragma unroll
+        for (int q = 0; q < ND; q++) qd[q] = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int x = x0 + i;
+            const int xs = max(0, x - n);
+            int fsum[C], fcnt;
+            if constexpr (C == 3) {
+                fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)(aI.d[0] & 0xffffu);
+                fsum[1] = (int)(aL.d[0] >> 16) + (int)(aI.d[0] >> 16);
+                fsum[2] = (int)(aL.d[1] & 0xffffu) + (int)(aI.d[1] & 0xffffu);
+                fcnt = (int)(aL.d[1] >> 16);
+                if constexpr (NH == 2) {
+                    fsum[0] += (int)(aR.d[0] & 0xffffu); fsum[1] += (int)(aR.d[0] >> 16);
+                    fsum[2] += (int)(aR.d[1] & 0xffffu); fcnt += (int)(aR.d[1] >> 16);
+                }
+            } else {
+                fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)aI.d[0];
+                fcnt = (int)(aL.d[0] >> 16);
+                if constexpr (NH == 2) { fsum[0] += (int)(aR.d[0] & 0xffffu); fcnt += (int)(aR.d[0] >> 16); }
+            }
+            const int cnt = fcnt + (y - ys) * (x - xs);
+            const float rc = __builtin_amdgcn_rcpf((float)max(cnt, 1));   // 1 ulp: inside div_small's margin
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const unsigned q = cnt > 0 ? div_small(fsum[c], rc) : 0u;
+                const int jb = i * C + c;
+                qd[jb >> 2] |= q << (8 * (jb & 3));
+            }
+            if (i + 1 < P) {      // slide to pixel x+1 (own columns' entries come from registers)
+                if constexpr (NH == 2) {
+                    eadd(aL, firE[i]); esub(aL, lds_ld(firA, x - n));
+                    eadd(aR, lds_ld(firA, x + n)); esub(aR, firE[i]);
+                } else {
+                    eadd(aL, lds_ld(firA, x + n)); esub(aL, lds_ld(firA, x - n));
+                }
+                eadd(aI, iirE[i]); esub(aI, lds_ld(iirA, x - n));
+            }
+        }
+        // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient
+        unsigned res[ND];
+        {
+            const unsigned on = on_bytes(r_cur.m[0]);
+            if constexpr (C == 3) {
+                const unsigned e0 = __builtin_amdgcn_perm(0u, on, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on, 0x02020101u),
+                               e2 = __builtin_amdgcn_perm(0u, on, 0x03030302u);
+                res[0] = ((r_cur.px[0] & e0) | (qd[0] & ~e0)) & pxm[0];
+                res[1] = ((r_cur.px[1] & e1) | (qd[1] & ~e1)) & pxm[1];
+                res[2] = ((r_cur.px[2] & e2) | (qd[2] & ~e2)) & pxm[2];
+            } else {
+                res[0] = ((r_cur.px[0] & on) | (qd[0] & ~on)) & pxm[0];
+            }
+        }
+        if (act) {
+            uint8_t *o = out + (size_t)y * opitch + (size_t)x0 * C;
+            if (x0 + P <= w) {
+#pragma unroll
+                for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+            } else {
+                const int nbytes = (w - x0) * C;
+#pragma unroll
+                for (int j = 0; j < P * C; j++)
+                    if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ND; q++) prev[q] = res[q];
+        lds_barrier();         // everyone is done reading the LDS rows
+
+        r_enter = n_enter; r_leave = n_leave; r_cur = n_cur;
+#pragma unroll
+        for (int q = 0; q < ND; q++) o_leave[q] = n_oleave[q];
     }
 }
 
@@ -292,8 +601,25 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
         else if (g.P == 8) OPT_LAUNCH(CC, 8, 1024, NAME);                           \
         else OPT_LAUNCH(CC, 16, 1024, NAME);                                        \
     } while (0)
-    if (c == 3) OPT_PICK(3, "optimise_rgb");
+#define OPT_PACKED(CC, NHH, MT, NAME)                                                                    \
+    do {                                                                                                \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_packed_kernel<CC, NHH, MT>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));           \
+        LAUNCH(ctx, s, NAME, alg,                                                                       \
+               hipLaunchKernelGGL((optimise_packed_kernel<CC, NHH, MT>), dim3(njobs), dim3(g.T), g.lds, s, d_jobs)); \
+    } while (0)
+    if (g.P == 4 && n_max <= 11) {
+        // 16-bit lane capacity: one FIR accumulator up to n=8, two halves up to n=11
+        if (c == 3) {
+            if (n_max <= 8) { if (g.T <= 512) OPT_PACKED(3, 1, 512, "optimise_rgb"); else OPT_PACKED(3, 1, 1024, "optimise_rgb"); }
+            else { if (g.T <= 512) OPT_PACKED(3, 2, 512, "optimise_rgb"); else OPT_PACKED(3, 2, 1024, "optimise_rgb"); }
+        } else {
+            if (n_max <= 8) { if (g.T <= 512) OPT_PACKED(1, 1, 512, "optimise_gray"); else OPT_PACKED(1, 1, 1024, "optimise_gray"); }
+            else { if (g.T <= 512) OPT_PACKED(1, 2, 512, "optimise_gray"); else OPT_PACKED(1, 2, 1024, "optimise_gray"); }
+        }
+    } else if (c == 3) OPT_PICK(3, "optimise_rgb");
     else OPT_PICK(1, "optimise_gray");
+#undef OPT_PACKED
 #undef OPT_PICK
 #undef OPT_LAUNCH
     return 0;

@@ -107,10 +107,50 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-template <int C>
+// unaligned 32-bit load (gfx950 global loads accept any byte address)
+typedef unsigned __attribute__((aligned(1))) unsigned_u1;
+__device__ __forceinline__ unsigned ld_u32(const uint8_t *p) { return *reinterpret_cast<const unsigned_u1 *>(p); }
+
+// Horizontal pass: one lane per output pixel.  The coefficient table is stored transposed
+// (kkT[tap][xx]) so that a wave's coefficient loads are contiguous; the window's bytes come in
+// as (unaligned) dwords.  Taps beyond a window's length have zero coefficients, so the fixed
+// MAXK-tap loop needs no masking (the bytes it over-reads lie inside the row pitch / PAD).
+template <int C, int MAXK>
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
                                                        uint8_t *dst, int dpitch, size_t dstride, int ow,
-                                                       const int32_t *bounds, const int32_t *kk, int ksize) {
+                                                       const int32_t *bounds, const int32_t *kkT) {
+    const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xx >= ow) return;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const int xmin = bounds[2 * xx];
+    const uint8_t *row = src + (size_t)y * spitch + (size_t)xmin * C;
+    constexpr int ND = (MAXK * C + 3) / 4;
+    unsigned v[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) v[d] = ld_u32(row + 4 * d);
+    int ss[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) ss[ch] = 1 << 21;
+#pragma unroll
+    for (int x = 0; x < MAXK; x++) {
+        const int kv = kkT[(size_t)x * ow + xx];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+            const int j = x * C + ch;
+            ss[ch] += (int)((v[j >> 2] >> (8 * (j & 3))) & 0xffu) * kv;
+        }
+    }
+    uint8_t *o = dst + (size_t)y * dpitch + (size_t)xx * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) o[ch] = clip8(ss[ch]);
+}
+
+// generic fallback (any ksize), row-major table
+template <int C>
+__global__ __launch_bounds__(256) void resize_h_generic_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
+                                                               uint8_t *dst, int dpitch, size_t dstride, int ow,
+                                                               const int32_t *bounds, const int32_t *kk, int ksize) {
     const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (xx >= ow) return;
     src += (size_t)blockIdx.z * sstride;
@@ -130,18 +170,34 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int s
     for (int ch = 0; ch < C; ch++) dst[(size_t)y * dpitch + (size_t)xx * C + ch] = clip8(ss[ch]);
 }
 
+// Vertical pass: one lane per 4 adjacent bytes of an output row (unaligned dword loads; the
+// per-row coefficients are wave-uniform -> scalar loads).
 __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *src, int spitch, size_t sstride, int row_bytes,
                                                        uint8_t *dst, int dpitch, size_t dstride, int oh,
                                                        const int32_t *bounds, const int32_t *kk, int ksize) {
-    const int j = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4, yy = blockIdx.y;
     if (j >= row_bytes) return;
     src += (size_t)blockIdx.z * sstride;
     dst += (size_t)blockIdx.z * dstride;
     const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
     const int32_t *k = kk + (size_t)yy * ksize;
-    int ss = 1 << 21;
-    for (int y = 0; y < n; y++) ss += (int)src[(size_t)(ymin + y) * spitch + j] * k[y];
-    dst[(size_t)yy * dpitch + j] = clip8(ss);
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21, s3 = 1 << 21;
+    const uint8_t *p = src + (size_t)ymin * spitch + j;
+    for (int y = 0; y < n; y++) {
+        const unsigned v = ld_u32(p + (size_t)y * spitch);
+        const int kv = k[y];
+        s0 += (int)(v & 0xffu) * kv; s1 += (int)((v >> 8) & 0xffu) * kv;
+        s2 += (int)((v >> 16) & 0xffu) * kv; s3 += (int)(v >> 24) * kv;
+    }
+    uint8_t *o = dst + (size_t)yy * dpitch + j;
+    if (j + 4 <= row_bytes) {
+        const unsigned r = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16) | ((unsigned)clip8(s3) << 24);
+        *reinterpret_cast<unsigned_u1 *>(o) = r;
+    } else {
+        o[0] = clip8(s0);
+        if (j + 1 < row_bytes) o[1] = clip8(s1);
+        if (j + 2 < row_bytes) o[2] = clip8(s2);
+    }
 }
 
 // Plan of one thumbnail: host tables + scratch sizes.  Built once per (shape, request).
@@ -161,13 +217,20 @@ int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
     }
     p.need_h = (p.ow != p.rw) || (bw != (float)p.ow);
     p.need_v = (p.oh != p.rh) || (bh != (float)p.oh);
-    if (p.need_h) p.ksh = bicubic_coeffs(p.rw, 0.f, bw, p.ow, p.bh_, p.kh_);
+    if (p.need_h) {
+        p.ksh = bicubic_coeffs(p.rw, 0.f, bw, p.ow, p.bh_, p.kh_);
+        if (p.ksh <= THUMB_MAXK) {                 // transposed, zero-padded to THUMB_MAXK taps
+            p.khT_.assign((size_t)THUMB_MAXK * p.ow, 0);
+            for (int xx = 0; xx < p.ow; xx++)
+                for (int x = 0; x < p.ksh; x++) p.khT_[(size_t)x * p.ow + xx] = p.kh_[(size_t)xx * p.ksh + x];
+        }
+    }
     if (p.need_v) p.ksv = bicubic_coeffs(p.rh, 0.f, bh, p.oh, p.bv_, p.kv_);
     return 0;
 }
 
 size_t ThumbPlan_table_bytes(const ThumbPlan &p) {
-    return (p.bh_.size() + p.kh_.size() + p.bv_.size() + p.kv_.size()) * sizeof(int32_t) + 64;
+    return (p.bh_.size() + p.kh_.size() + p.bv_.size() + p.kv_.size() + p.khT_.size()) * sizeof(int32_t) + 64;
 }
 
 // d_tables: device copy of [bh_, kh_, bv_, kv_] in that order (int32), made by the caller.
@@ -192,21 +255,35 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
         cur = scratch1; cw = p.rw; ch_ = p.rh;
     }
     const int32_t *d_bh = d_tables, *d_kh = d_bh + p.bh_.size(), *d_bv = d_kh + p.kh_.size(), *d_kv = d_bv + p.bv_.size();
+    const int32_t *d_khT = d_kv + p.kv_.size();
     if (p.need_h) {
         Plane o = p.need_v ? scratch2 : dst;
-        if (c == 3)
-            LAUNCH(ctx, s, "thumb_resize_h", red ? 0.0 : alg,
-                   hipLaunchKernelGGL(resize_h_kernel<3>, dim3(cdiv(p.ow, 256), ch_, npages), dim3(256), 0, s, cur.p, cur.pitch,
-                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
-        else
-            LAUNCH(ctx, s, "thumb_resize_h", red ? 0.0 : alg,
-                   hipLaunchKernelGGL(resize_h_kernel<1>, dim3(cdiv(p.ow, 256), ch_, npages), dim3(256), 0, s, cur.p, cur.pitch,
-                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
+        const dim3 grid(cdiv(p.ow, 256), ch_, npages);
+        const double a = red ? 0.0 : alg;
+        if (!p.khT_.empty()) {
+            if (c == 3)
+                LAUNCH(ctx, s, "thumb_resize_h", a,
+                       hipLaunchKernelGGL((resize_h_kernel<3, THUMB_MAXK>), grid, dim3(256), 0, s, cur.p, cur.pitch,
+                                          cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));
+            else
+                LAUNCH(ctx, s, "thumb_resize_h", a,
+                       hipLaunchKernelGGL((resize_h_kernel<1, THUMB_MAXK>), grid, dim3(256), 0, s, cur.p, cur.pitch,
+                                          cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));
+        } else {
+            if (c == 3)
+                LAUNCH(ctx, s, "thumb_resize_h", a,
+                       hipLaunchKernelGGL(resize_h_generic_kernel<3>, grid, dim3(256), 0, s, cur.p, cur.pitch, cur.stride, ch_,
+                                          o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
+            else
+                LAUNCH(ctx, s, "thumb_resize_h", a,
+                       hipLaunchKernelGGL(resize_h_generic_kernel<1>, grid, dim3(256), 0, s, cur.p, cur.pitch, cur.stride, ch_,
+                                          o.p, o.pitch, o.stride, p.ow, d_bh, d_kh, p.ksh));
+        }
         cur = o; cw = p.ow;
     }
     if (p.need_v) {
         LAUNCH(ctx, s, "thumb_resize_v", (red || p.need_h) ? 0.0 : alg,
-               hipLaunchKernelGGL(resize_v_kernel, dim3(cdiv(cw * c, 256), p.oh, npages), dim3(256), 0, s, cur.p, cur.pitch,
+               hipLaunchKernelGGL(resize_v_kernel, dim3(cdiv(cdiv(cw * c, 4), 256), p.oh, npages), dim3(256), 0, s, cur.p, cur.pitch,
                                   cur.stride, cw * c, dst.p, dst.pitch, dst.stride, p.oh, d_bv, d_kv, p.ksv));
     } else if (cur.p != dst.p) {
         for (int i = 0; i < npages; i++)

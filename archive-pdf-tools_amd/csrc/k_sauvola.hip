@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         for (int i = 0; i < K; i++) { ps[i] = ts; pq[i] = tq; ts += cs[i]; tq += cq[i]; }
         unsigned bs = wave_scan_incl(ts) - ts;
         unsigned bq = wave_scan_incl(tq) - tq;
-        __syncthreads();   // previous row's readers are done (single-wave workgroup)
+        lds_wave_sync();   // previous row's reads are done (single-wave workgroup)
 #pragma unroll
         for (int i = 0; i < K; i += 4) {
             uint4 a = make_uint4(bs + ps[i], bs + ps[i + 1], bs + ps[i + 2], bs + ps[i + 3]);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             *reinterpret_cast<uint4 *>(&Es[K * lane + i]) = a;
             *reinterpret_cast<uint4 *>(&Eq[K * lane + i]) = b;
         }
-        __syncthreads();
+        lds_wave_sync();
 
         // centre pixels of this row
         unsigned cv[K / 4];

@@ -35,6 +35,21 @@ void set_error(const char *fmt, ...);
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
+// fence for GLOBAL memory, i.e. `s_waitcnt vmcnt(0)`: in the row-sequential kernels that would expose
+// the full latency of the prefetched global loads and of the row's stores on every row.  These
+// kernels never exchange data between lanes through global memory, so only lgkmcnt must drain.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// same for a single-wave workgroup: LDS operations of one wave execute in order, only the
+// compiler and the lgkm counter need to be told
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+
 // All device images are pitched (pitch % 64 == 0) with PAD bytes of slack in
 // front of row 0 and behind the last row, so kernels may issue aligned dword
 // loads that straddle the row ends (the bytes are masked, never used).
@@ -188,9 +203,11 @@ struct HocrBox {
     uint8_t *mask;           // row 0 of the page's mask
     int mpitch;
     int page_end;            // index one past the last box of the same page
+    int overlapped;          // a later box of the page with a decision intersects this one
 };
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area);
 
+constexpr int THUMB_MAXK = 20;
 // thumbnail plan: host-side size rule + fixed-point coefficient tables
 struct ThumbPlan {
     int w = 0, h = 0, c = 1;
@@ -199,7 +216,7 @@ struct ThumbPlan {
     int fx = 1, fy = 1;       // Image.reduce factors
     int rw = 0, rh = 0;       // size after reduce
     int need_h = 0, need_v = 0, ksh = 0, ksv = 0;
-    std::vector<int32_t> bh_, kh_, bv_, kv_;
+    std::vector<int32_t> bh_, kh_, bv_, kv_, khT_;   // khT_: kh_ transposed, padded to THUMB_MAXK taps
 };
 int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h);
 size_t ThumbPlan_table_bytes(const ThumbPlan &p);
