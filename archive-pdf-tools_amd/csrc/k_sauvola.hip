@@ -267,7 +267,7 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
         LAUNCH(ctx, s, "sauvola", alg_bytes,
                hipLaunchKernelGGL((sauvola_kernel<K, false>), grid, dim3(64), 0, s, h_jobs[0], nullptr, P));
     } else {
-        LAUNCH(ctx, s, "sauvola_boxes", alg_bytes,
+        LAUNCH(ctx, s, h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola", alg_bytes,
                hipLaunchKernelGGL((sauvola_kernel<K, true>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
     }
     return 0;

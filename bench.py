@@ -97,14 +97,13 @@ def main():
     lib = _lib.load()
     info = ctx.info()
 
-    # work queue: rank 0 decides the page seeds and broadcasts the descriptor table (bytes, not pixels)
+    # work queue: rank 0 owns the descriptor table and broadcasts it over RCCL (bytes, not pixels);
+    # every rank then takes the pages i with i mod world == rank
     if dist is not None:
-        import torch
-        desc = torch.zeros(4, dtype=torch.int64, device='cuda')
-        if rank == 0:
-            desc[:] = torch.tensor([W, H, a.pages, DISTINCT])
-        dist.broadcast(desc, 0)
-        assert desc.tolist() == [W, H, a.pages, DISTINCT]
+        from mrchip import dist as mdist
+        desc = mdist.broadcast_descriptor(dist, {'w': W, 'h': H, 'pages_per_rank': a.pages, 'distinct': DISTINCT}
+                                          if rank == 0 else None)
+        assert (desc['w'], desc['h'], desc['pages_per_rank']) == (W, H, a.pages)
 
     host_pages = make_pages(DISTINCT, rank)
     window = 51                                    # dpi=None (bin/compress-pdf-images:66-70)
@@ -152,10 +151,8 @@ def main():
     prof = ctx.prof_report()
     ctx.prof_enable(False)
     if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        from mrchip import dist as mdist
+        dt = mdist.max_over_ranks(dist, dt)
 
     # untimed: parity evidence + PCIe-inclusive drop-in rate on rank 0
     extra = {}
@@ -178,17 +175,35 @@ def main():
 
     total_pages = a.pages * a.steps * world
     value = total_pages / dt
+    def roofline_of(name):
+        r = prof[name]
+        ms = r['ms'] / r['launches']
+        alg = r['alg_bytes'] / r['launches']
+        achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(name, alg),
+                'avg_launch_ms': round(ms, 4), 'launches': r['launches'], 'alg_bytes_per_launch': alg}
+
+    def pmc_traffic(name, alg_per_launch):
+        """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
+        2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size."""
+        sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
+               'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
+            d = json.load(open(f))
+            for k, v in d['kernels'].items():
+                if sym in k and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
+                    return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch'])
+        except Exception:
+            pass
+        return None
+
     # dominant kernel by GPU time
     dom = max(prof.items(), key=lambda kv: kv[1]['ms']) if prof else None
-    roof = None
-    if dom:
-        name, r = dom
-        ms = r['ms'] / r['launches']
-        achieved = r['alg_bytes'] / r['launches'] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        roof = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
-                'avg_launch_ms': round(ms, 4), 'launches': r['launches'],
-                'alg_bytes_per_launch': r['alg_bytes'] / r['launches']}
+    roof = roofline_of(dom[0]) if dom else None
+    sauvola_roof = roofline_of('sauvola') if 'sauvola' in prof else None
     kernels = {k: {'ms_per_launch': round(v['ms'] / v['launches'], 4), 'launches': v['launches'],
                    'alg_GBps': round(v['alg_bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in sorted(prof.items())}
     if rank == 0:
@@ -201,7 +216,9 @@ def main():
                                    'bg_downsample=3, denoise fast, full create_mrc_hocr_components',
                        'pages_per_gpu_per_step': a.pages, 'batches_in_flight': nb, 'distinct_pages': DISTINCT,
                        'hocr_boxes_per_page': int(len(host_pages[0][2])), 'sharding': 'pages round-robin over ranks'},
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'device': info['name'].strip(),
+            'roofline': roof, 'cpu_baseline': cpu,
+            'sauvola_roofline': sauvola_roof,      # BASELINE.json also names "Sauvola HBM GB/s"
+            'kernels': kernels, 'device': info['name'].strip(),
         }
         line.update(extra)
         print(json.dumps(line))

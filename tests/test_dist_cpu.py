@@ -1,0 +1,64 @@
+"""CPU suite: the N>1 logic of bench.py (page sharding, descriptor broadcast, max-over-ranks
+timing) with world_size-2 gloo processes -- no GPU, no pixels across ranks."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.path.join(%r, 'archive-pdf-tools_amd'))
+    from mrchip import dist as mdist
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # rank 0 owns the work queue; every rank derives its own shard from the broadcast descriptor
+    desc = mdist.broadcast_descriptor(dist, {'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202} if rank == 0 else None)
+    mine = mdist.shard_pages(desc['pages'], rank, world)
+    elapsed = mdist.max_over_ranks(dist, 1.0 + rank)            # slowest rank defines the step time
+    gathered = mdist.gather_records(dist, [{'page': p, 'rank': rank} for p in mine])
+    if rank == 0:
+        print(json.dumps({'desc': desc, 'elapsed': elapsed, 'records': gathered}))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['desc'] == {'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202}
+    assert out['elapsed'] == 2.0
+    pages = sorted(rec['page'] for rec in out['records'])
+    assert pages == list(range(10))                              # every page exactly once
+    for rec in out['records']:
+        assert rec['rank'] == rec['page'] % 2                    # round-robin page i -> rank i mod G
+
+
+def test_shard_pages_properties():
+    sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+    from mrchip import dist as mdist
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 7, 8, 512):
+            shards = [mdist.shard_pages(n, r, world) for r in range(world)]
+            assert sorted(p for s in shards for p in s) == list(range(n))
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
