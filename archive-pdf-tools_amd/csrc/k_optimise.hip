@@ -310,17 +310,18 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
 // So every vertical update, every horizontal slide is a plain 32-bit add/sub on packed pairs
 // (lane-wise non-negative results: add first, subtract what was added before), pixel bytes are
 // routed into the lanes with v_perm_b32, and the publish step is a straight ds_write_b64.
-template <int C, int NH, int MAXT>
-__global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
+// NCT: n_size as a compile-time constant (the reference's 3 and 10: every window loop unrolls and
+// every LDS access becomes `thread base + immediate offset`), or -1 for a run-time n.
+template <int C, int NH, int NCT>
+__device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem) {
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
     constexpr int ND = P * C / 4;                 // dwords of pixel bytes per thread-row
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const OptJob J = jobs[blockIdx.x];
     const uint8_t *__restrict__ mask = J.mask;
     const uint8_t *__restrict__ img = J.img;
     uint8_t *out = J.out;
-    const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h, n = J.n;
+    const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h;
+    const int n = NCT >= 0 ? NCT : J.n;
     const unsigned invm = J.invert ? 0xffffffffu : 0u;
 
     const int npad = n;
@@ -333,8 +334,11 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
     unsigned *iirA = firA + (size_t)nelem * EW;
     for (int i = t; i < 2 * nelem * EW; i += T) firA[i] = 0;
     __syncthreads();
-    // column c -> dword index of its entry (one pad entry per 4 columns: conflict-free lane stride)
-    auto eidx = [&](int col) { const int e = col + npad; return (e + (e >> 2)) * EW; };
+    // column c -> dword index of its entry (one pad entry per 4 columns: conflict-free lane stride).
+    // With c = x0 + j and x0 = 4t: index = (5t + d + (d>>2)) * EW, d = j + n >= 0 -- `5t*EW` is the
+    // thread's base, the rest folds to an immediate when n is a compile-time constant.
+    const int ebase = 5 * t * EW;
+    auto eidx = [&](int col) { const int d = col - x0 + npad; return ebase + (d + (d >> 2)) * EW; };
 
     const bool act = x0 < w;
     unsigned colm = 0, pxm[ND];                   // 0xFF per valid column / per valid pixel byte
@@ -482,9 +486,20 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
         Ent aL, aR, aI;
 #pragma unroll
         for (int k = 0; k < EW; k++) { aL.d[k] = 0; aR.d[k] = 0; aI.d[k] = 0; }
-        for (int j = -n; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
-        for (int j = 0; j < n; j++) {
-            if constexpr (NH == 2) eadd(aR, lds_ld(firA, x0 + j)); else eadd(aL, lds_ld(firA, x0 + j));
+        if constexpr (NCT >= 0) {
+#pragma unroll
+            for (int j = -NCT; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
+#pragma unroll
+            for (int j = 0; j < NCT; j++) {
+                // own columns come from registers
+                const Ent e = j < P ? firE[j < P ? j : 0] : lds_ld(firA, x0 + j);
+                if constexpr (NH == 2) eadd(aR, e); else eadd(aL, e);
+            }
+        } else {
+            for (int j = -n; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
+            for (int j = 0; j < n; j++) {
+                if constexpr (NH == 2) eadd(aR, lds_ld(firA, x0 + j)); else eadd(aL, lds_ld(firA, x0 + j));
+            }
         }
 
         unsigned qd[ND];
@@ -561,6 +576,18 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
 #pragma unroll
         for (int q = 0; q < ND; q++) o_leave[q] = n_oleave[q];
     }
+}
+
+template <int C, int NH, int MAXT>
+__global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const OptJob J = jobs[blockIdx.x];
+    // wave-uniform dispatch on the job's n_size: the reference's two values get unrolled bodies
+    if (J.n == 3) optimise_packed_rows<C, NH, 3>(J, smem);            // fg, mrc.py:413/415
+    else if (J.n == 10) {
+        if constexpr (NH == 2) optimise_packed_rows<C, NH, 10>(J, smem);   // bg, mrc.py:447/449
+        else optimise_packed_rows<C, NH, -1>(J, smem);
+    } else optimise_packed_rows<C, NH, -1>(J, smem);
 }
 
 struct OptGeom { int P, T; size_t lds; };
