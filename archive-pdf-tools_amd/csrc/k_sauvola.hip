@@ -16,9 +16,11 @@
 // comparison, which is evaluated in fp64 in the reference's operation order
 // with contraction off.
 //
-// HBM traffic per pixel: 1 B read (+ halo re-reads served by L2: each input row
-// is touched three times by the same wave -- entering, centre, leaving) + 1 B
-// written.  Algorithmic bytes: 2*w*h.
+// Traffic per pixel: 1 B written + 1 B read x (strip-halo overlap CW/(CW-ww)) x (tile warm-up
+// (th+wh)/th) x 3 (entering, centre and leaving use of a row; the two re-reads are 25 rows old and
+// come back from L2 / Infinity Cache).  Algorithmic bytes: 2*w*h.
+#include <cstdlib>
+
 #include "mrchip_internal.h"
 
 namespace mrchip {
@@ -67,24 +69,38 @@ __device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) 
     if constexpr (K == 16) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 }
 
-// the reference's decision (pyx:143-153) for one pixel; returns `form`
-__device__ __forceinline__ bool sauvola_form(unsigned S, unsigned Q, unsigned count, unsigned px,
-                                             double k, double km1, double k2) {
-    double mean = (double)(S / count);              // C integer division (cdivision)
-    double qd = (double)(Q / count);
-    double mm = __dmul_rn(mean, mean);
-    double variance = __dsub_rn(qd, mm);
-    double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
-    double lhs = __dmul_rn(tmp, tmp);
-    double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
+// floor(N / c) for c >= 1: fp32 estimate (|error| < 1 for N < 2^32, quotient < 2^17) + one exact
+// correction step in wrap-around 32-bit arithmetic.  rc = 1/c to 1 ulp.
+__device__ __forceinline__ unsigned div_exact(unsigned N, unsigned c, float rc) {
+    unsigned q = (unsigned)((float)N * rc);
+    int rem = (int)(N - __umul24(q, c));       // q < 2^17, c < 2^17: the 24-bit multiply is exact mod 2^32
+    q += (rem >= (int)c) ? 1u : 0u;
+    q -= (rem < 0) ? 1u : 0u;
+    return q;
+}
+
+// the reference's decision (pyx:143-153) for one pixel; returns `form`.  mean and Q/count are the
+// truncated integer quotients (cdivision), everything after that is fp64 in the reference's order.
+__device__ __forceinline__ bool sauvola_form(unsigned mean_i, unsigned qd_i, unsigned px, double k, double km1, double k2) {
+    const double mean = (double)mean_i;
+    const double mm = (double)(mean_i * mean_i);          // exact: < 2^16
+    const double variance = (double)qd_i - mm;            // exact integers in fp64
+    const double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
+    const double lhs = __dmul_rn(tmp, tmp);
+    const double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
     if (k >= 0) return (tmp <= 0) || (lhs <= rhs);
     return (tmp <= 0) && (lhs >= rhs);
 }
 
+// Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
+// (wh-1)-row warm-up).  (An LDS ring of the last wh rows was tried: it removes the re-reads but
+// caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
 template <int K, bool MULTI>
 __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
     constexpr int CW = 64 * K;
+    constexpr int KD = K / 4;
+    constexpr int PF = 4;                              // rows in flight
     __shared__ __attribute__((aligned(16))) unsigned Es[CW];
     __shared__ __attribute__((aligned(16))) unsigned Eq[CW];
 
@@ -106,9 +122,9 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
     }
     const int c0 = Xa + K * lane;          // this lane's first column
     // per-byte validity mask of the K columns (columns outside [0,w) contribute 0)
-    unsigned vmask[K / 4];
+    unsigned vmask[KD];
 #pragma unroll
-    for (int q = 0; q < K / 4; q++) {
+    for (int q = 0; q < KD; q++) {
         unsigned m = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -118,62 +134,95 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         vmask[q] = m;
     }
     const uint8_t *src0 = job.src + c0;
+    // all outputs of this strip see the full window width -> count is wave-uniform per row
+    const bool full_cols = (X0 - l + 1 >= 0) && (X0 + nout - 1 + r <= w - 1);
 
     unsigned cs[K], cq[K];
 #pragma unroll
     for (int i = 0; i < K; i++) { cs[i] = 0; cq[i] = 0; }
 
-    auto add_row = [&](int yy, bool plus) {
-        unsigned wv[K / 4];
-        load_px<K>(src0 + (size_t)yy * job.src_pitch, wv);
+    auto acc_row = [&](const unsigned (&wv)[KD], bool plus) {
 #pragma unroll
-        for (int q = 0; q < K / 4; q++) {
-            unsigned v = wv[q] & vmask[q];
+        for (int q = 0; q < KD; q++) {
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                unsigned p = (v >> (8 * b)) & 0xffu;
+                unsigned p = (wv[q] >> (8 * b)) & 0xffu;
                 if (plus) { cs[4 * q + b] += p; cq[4 * q + b] += p * p; }
                 else      { cs[4 * q + b] -= p; cq[4 * q + b] -= p * p; }
             }
         }
     };
-
-    // warm-up: rows [Y0-o, Y0+u-1] clipped to the image
-    for (int yy = max(0, Y0 - o); yy < min(h, Y0 + u); yy++) add_row(yy, true);
+    auto gload = [&](int yy, unsigned (&wv)[KD]) {       // masked row from global; rows outside the image are zero
+        if (yy >= 0 && yy < h) {
+            load_px<K>(src0 + (size_t)yy * job.src_pitch, wv);
+#pragma unroll
+            for (int q = 0; q < KD; q++) wv[q] &= vmask[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < KD; q++) wv[q] = 0;
+        }
+    };
+    // warm-up: rows [Y0-o, Y0+u-1] (clipped) enter the sums
+    for (int yy = max(0, Y0 - o); yy < min(h, Y0 + u); yy++) {
+        unsigned wv[KD];
+        gload(yy, wv);
+        acc_row(wv, true);
+    }
+    // three register queues, PF rows deep: entering rows y+u, leaving rows y-o, centre rows y.
+    // Every address is known in advance, so the loads run PF rows ahead of their use and the
+    // serial chain of a row never waits for memory (leaving / centre rows come back from L2/MALL).
+    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD];
+#pragma unroll
+    for (int d = 0; d < PF; d++) {
+        gload(Y0 + u + d, qe[d]);
+        gload(Y0 - o + d, ql[d]);
+        gload(Y0 + d, qc[d]);
+    }
 
     const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
     const bool do_or = (P.flags & SAUVOLA_OR) != 0;
     unsigned ones_a = 0, ones_b = 0;
 
     for (int y = Y0; y < Y0 + rows; y++) {
-        if (y + u < h) add_row(y + u, true);
-        if (y - o >= 0) add_row(y - o, false);
+        // ---- heads of the queues, then refill PF rows ahead ----
+        unsigned ev[KD], lv[KD], cv[KD];
+#pragma unroll
+        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; }
+#pragma unroll
+        for (int d = 0; d + 1 < PF; d++)
+#pragma unroll
+            for (int q = 0; q < KD; q++) { qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q]; }
+        gload(y + u + PF, qe[PF - 1]);
+        gload(y - o + PF, ql[PF - 1]);
+        gload(y + PF, qc[PF - 1]);
+        acc_row(ev, true);                 // rows outside the image were loaded as zeros
+        acc_row(lv, false);
         const int nrows = min(y + u, h - 1) - max(y - o, -1);
 
         // exclusive prefix over the strip's columns
-        unsigned ps[K], pq[K];
+        unsigned ps[K], pqx[K];
         unsigned ts = 0, tq = 0;
 #pragma unroll
-        for (int i = 0; i < K; i++) { ps[i] = ts; pq[i] = tq; ts += cs[i]; tq += cq[i]; }
+        for (int i = 0; i < K; i++) { ps[i] = ts; pqx[i] = tq; ts += cs[i]; tq += cq[i]; }
         unsigned bs = wave_scan_incl(ts) - ts;
         unsigned bq = wave_scan_incl(tq) - tq;
-        lds_wave_sync();   // previous row's reads are done (single-wave workgroup)
+        lds_wave_sync();                   // previous row's LDS reads are done
 #pragma unroll
         for (int i = 0; i < K; i += 4) {
             uint4 a = make_uint4(bs + ps[i], bs + ps[i + 1], bs + ps[i + 2], bs + ps[i + 3]);
-            uint4 b = make_uint4(bq + pq[i], bq + pq[i + 1], bq + pq[i + 2], bq + pq[i + 3]);
+            uint4 b = make_uint4(bq + pqx[i], bq + pqx[i + 1], bq + pqx[i + 2], bq + pqx[i + 3]);
             *reinterpret_cast<uint4 *>(&Es[K * lane + i]) = a;
             *reinterpret_cast<uint4 *>(&Eq[K * lane + i]) = b;
         }
         lds_wave_sync();
 
-        // centre pixels of this row
-        unsigned cv[K / 4];
-        load_px<K>(src0 + (size_t)y * job.src_pitch, cv);
+        // wave-uniform count / reciprocal when every output of the strip has the full window width
+        const unsigned ucount = (unsigned)(P.ww * nrows);
+        const float urc = __builtin_amdgcn_rcpf((float)ucount);
 
-        unsigned outa[K / 4], outb[K / 4];
+        unsigned outa[KD], outb[KD];
 #pragma unroll
-        for (int q = 0; q < K / 4; q++) { outa[q] = 0; outb[q] = 0; }
+        for (int q = 0; q < KD; q++) { outa[q] = 0; outb[q] = 0; }
         bool any = false, all = true;
 #pragma unroll
         for (int i = 0; i < K; i++) {
@@ -185,18 +234,25 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 const int ci = K * lane + i;
                 const unsigned S = Es[ci + r + 1] - Es[ci - l + 1];
                 const unsigned Q = Eq[ci + r + 1] - Eq[ci - l + 1];
-                const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
-                const unsigned count = (unsigned)(ncols * nrows);
+                unsigned count = ucount;
+                float rc = urc;
+                if (!full_cols) {
+                    const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
+                    count = (unsigned)(ncols * nrows);
+                    rc = __builtin_amdgcn_rcpf((float)count);
+                }
                 const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
-                bool form = sauvola_form(S, Q, count, px, P.k, P.km1, P.k2);
+                const unsigned mean_i = div_exact(S, count, rc);            // pyx:144 (cdivision)
+                const unsigned qd_i = div_exact(Q, count, rc);              // pyx:145
+                bool form = sauvola_form(mean_i, qd_i, px, P.k, P.km1, P.k2);
                 unsigned bit = (form ? 0u : 1u) ^ (invert ? 1u : 0u);   // pyx:153 (+ mrc.py:85)
                 outa[i / 4] |= bit << (8 * (i & 3));
                 ones_a += bit;
                 if (job.dst_inv) {
                     // the same window on the image 255-p (mrc.py:224, 235)
-                    const unsigned Si = 255u * count - S;
-                    const unsigned Qi = 65025u * count - 510u * S + Q;
-                    bool fi = sauvola_form(Si, Qi, count, 255u - px, P.k, P.km1, P.k2);
+                    const unsigned Si = __umul24(255u, count) - S;
+                    const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
+                    bool fi = sauvola_form(div_exact(Si, count, rc), div_exact(Qi, count, rc), 255u - px, P.k, P.km1, P.k2);
                     unsigned bi = (fi ? 0u : 1u) ^ (invert ? 1u : 0u);
                     outb[i / 4] |= bi << (8 * (i & 3));
                     ones_b += bi;
@@ -208,7 +264,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             const bool aligned = (reinterpret_cast<uintptr_t>(d) & 3u) == 0;
             if (all && aligned) {
 #pragma unroll
-                for (int q = 0; q < K / 4; q++) {
+                for (int q = 0; q < KD; q++) {
                     unsigned *dp = reinterpret_cast<unsigned *>(d) + q;
                     *dp = do_or ? (*dp | outa[q]) : outa[q];
                 }
@@ -226,7 +282,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 uint8_t *e = job.dst_inv + (size_t)y * job.dst_pitch + c0;
                 if (all && aligned) {
 #pragma unroll
-                    for (int q = 0; q < K / 4; q++) reinterpret_cast<unsigned *>(e)[q] = outb[q];
+                    for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(e)[q] = outb[q];
                 } else {
 #pragma unroll
                     for (int i = 0; i < K; i++) {
@@ -257,10 +313,13 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
         set_error("sauvola: window width %d too large for the %d-column strip", P.ww, CW);
         return MRCHIP_E_UNSUPPORTED;
     }
-    // rows per tile: enough tiles to fill the chip, but amortise the (wh-1)-row warm-up
+    // rows per tile: tall tiles amortise the (wh-1)-row warm-up; shrink only while the launch
+    // would leave the chip short of waves
     int strips = cdiv(maxw, P.two);
-    int th = 64;
-    while (th > 16 && (long long)strips * cdiv(maxh, th) * njobs < 2048) th >>= 1;
+    // measured flat between 32 and 512 rows per tile on 64-page batches; 1024 starves the chip
+    int th = 256;
+    while (th > 32 && (long long)strips * cdiv(maxh, th) * njobs < 8192) th >>= 1;
+    if (const char *e = getenv("MRCHIP_SAUVOLA_TH")) { int v = atoi(e); if (v >= 8) th = v; }   // tuning knob
     P.th = th;
     dim3 grid(strips, cdiv(maxh, th), njobs);
     if (njobs == 1 && !d_jobs) {
@@ -279,8 +338,9 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
                        int njobs, int ww, int wh, double k, double R, int flags) {
     if (njobs <= 0) return 0;
     if (ww < 1 || wh < 1) { set_error("sauvola: window must be >= 1"); return MRCHIP_E_ARG; }
-    if ((long long)ww * wh > 66051) {
-        set_error("sauvola: window %dx%d exceeds the 32-bit sum-of-squares range (area <= 66051)", ww, wh);
+    if ((long long)ww * wh > 65792) {
+        // S = sum of a window < 2^24 (24-bit multiplies, exact fp32) and Q < 2^32
+        set_error("sauvola: window %dx%d exceeds the supported area (<= 65792 = 256x257)", ww, wh);
         return MRCHIP_E_UNSUPPORTED;
     }
     SauvolaParams P;
