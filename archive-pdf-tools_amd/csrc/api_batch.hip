@@ -362,6 +362,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     // ---- create_threshold_mask (mrc.py:300-329) ----
     GaussW *hg = reinterpret_cast<GaussW *>(b->hctrl + L.gauss);
     bool any_blur = false;
+    int max_radius = 0;
     for (int i = 0; i < N; i++) {
         memset(&hg[i], 0, sizeof(GaussW));
         hg[i].w[0] = 1.0;                                               // radius 0: identity
@@ -382,6 +383,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
             }
             hg[i].radius = r;
             if (r > 0) any_blur = true;
+            max_radius = std::max(max_radius, r);
         }
     }
     Plane thr_src = b->gray;
@@ -389,7 +391,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         GaussW *dg = reinterpret_cast<GaussW *>(dctrl + L.gauss);
         HIP_TRY(hipMemcpyAsync(dg, hg, (size_t)N * sizeof(GaussW), hipMemcpyHostToDevice, s));
         TRY(launch_gaussian_batch(ctx, s, b->gray, b->blur.pl, w, h, dg, b->gtmp.as<float>(), b->gtmp_pitch,
-                                  b->gtmp_stride, N));                                                   // mrc.py:311, 325
+                                  b->gtmp_stride, N, max_radius));                                       // mrc.py:311, 325
         thr_src = b->blur.pl;
     }
     SauvolaJob *hj = reinterpret_cast<SauvolaJob *>(b->hctrl + L.pjobs);

@@ -163,7 +163,7 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
     HIP_TRY(hipStreamSynchronize(s));
     Plane pa, pb;
     pa.p = a.p; pa.pitch = a.pitch; pb.p = b.p; pb.pitch = b.pitch;
-    TRY(launch_gaussian_batch(ctx, s, pa, pb, w, h, gw.as<GaussW>(), tmp.as<float>(), tp, 0, 1));
+    TRY(launch_gaussian_batch(ctx, s, pa, pb, w, h, gw.as<GaussW>(), tmp.as<float>(), tp, 0, 1, radius));
     TRY(download_2d(s, out, w, b.p, b.pitch, w, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -71,6 +71,82 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
     dst[(size_t)y * dpitch + x] = (uint8_t)(float)acc;      // float32 result, astype(uint8) truncation
 }
 
+// Fused separable blur for the radii the pipeline produces (sigma_est*0.1 -> radius <= 8): one
+// workgroup blurs a TW x TH tile.  Vertical pass straight from global memory (4 adjacent columns per
+// lane, aligned dword loads) into a float32 LDS tile that includes the 2r halo columns; horizontal
+// pass out of LDS (consecutive lanes -> consecutive floats, conflict-free); result bytes staged in
+// LDS and written as whole dwords.  Same arithmetic, same rounding points as the two-pass kernels
+// (float32 intermediate between the passes) -- the f32 scratch image never goes to HBM:
+// 2 B/px of traffic instead of 10.
+constexpr int GF_TW = 256, GF_TH = 32, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4;
+
+__global__ __launch_bounds__(256) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride, uint8_t *dst,
+                                                          int dpitch, size_t dstride, int w, int h, const GaussW *Gs) {
+    __shared__ float tmpT[GF_TH][GF_LW];
+    __shared__ __attribute__((aligned(4))) uint8_t outT[GF_TH][GF_TW];
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const GaussW &G = Gs[blockIdx.z];
+    const int r = G.radius;
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * GF_TW, Y0 = blockIdx.y * GF_TH;
+    const int Xa = max(0, X0 - r) & ~3;                       // first tile column, dword aligned
+    const int Xe = min(w, X0 + GF_TW + r);                    // one past the last needed column
+    const int ngroups = (Xe - Xa + 3) >> 2;
+    const int nrows = min(GF_TH, h - Y0);
+    // ---- vertical pass: global -> float32 LDS tile ----
+    for (int item = tid; item < ngroups * nrows; item += 256) {
+        const int g = item % ngroups, ty = item / ngroups;
+        const int x = Xa + 4 * g, y = Y0 + ty;
+        auto ld4 = [&](int yy) { return *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x); };
+        const unsigned c = ld4(y);
+        const double wc = G.w[r];
+        double a0 = __dmul_rn((double)(c & 0xffu), wc), a1 = __dmul_rn((double)((c >> 8) & 0xffu), wc);
+        double a2 = __dmul_rn((double)((c >> 16) & 0xffu), wc), a3 = __dmul_rn((double)(c >> 24), wc);
+        for (int j = -r; j < 0; j++) {
+            const unsigned p = ld4(reflect_idx(y + j, h)), q = ld4(reflect_idx(y - j, h));
+            const double wj = G.w[r + j];
+            a0 = __dadd_rn(a0, __dmul_rn(__dadd_rn((double)(p & 0xffu), (double)(q & 0xffu)), wj));
+            a1 = __dadd_rn(a1, __dmul_rn(__dadd_rn((double)((p >> 8) & 0xffu), (double)((q >> 8) & 0xffu)), wj));
+            a2 = __dadd_rn(a2, __dmul_rn(__dadd_rn((double)((p >> 16) & 0xffu), (double)((q >> 16) & 0xffu)), wj));
+            a3 = __dadd_rn(a3, __dmul_rn(__dadd_rn((double)(p >> 24), (double)(q >> 24)), wj));
+        }
+        float *t = &tmpT[ty][4 * g];
+        t[0] = (float)a0; t[1] = (float)a1; t[2] = (float)a2; t[3] = (float)a3;
+    }
+    __syncthreads();
+    // ---- horizontal pass: LDS -> result bytes in LDS ----
+    {
+        const int x = X0 + tid;
+        if (x < w) {
+            const bool interior = (x - r >= 0) && (x + r < w);
+            for (int ty = 0; ty < nrows; ty++) {
+                const float *row = &tmpT[ty][0] - Xa;             // row[c] = intermediate of image column c
+                double acc = __dmul_rn((double)row[x], G.w[r]);
+                if (interior) {
+                    for (int j = -r; j < 0; j++)
+                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[x + j], (double)row[x - j]), G.w[r + j]));
+                } else {
+                    for (int j = -r; j < 0; j++)
+                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[reflect_idx(x + j, w)],
+                                                                 (double)row[reflect_idx(x - j, w)]), G.w[r + j]));
+                }
+                outT[ty][tid] = (uint8_t)(float)acc;              // float32 result, astype(uint8) truncation
+            }
+        }
+    }
+    __syncthreads();
+    // ---- store: whole dwords ----
+    for (int k = tid; k < nrows * (GF_TW / 4); k += 256) {
+        const int ty = k / (GF_TW / 4), q = k % (GF_TW / 4);
+        const int x = X0 + 4 * q, y = Y0 + ty;
+        if (x >= w) continue;
+        uint8_t *o = dst + (size_t)y * dpitch + x;
+        if (x + 4 <= w) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(&outT[ty][4 * q]);
+        else for (int i = 0; x + i < w; i++) o[i] = outT[ty][4 * q + i];
+    }
+}
+
 int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
     // scipy _gaussian_kernel1d with libm's exp (numpy's exp may differ in the last bit)
     int radius = (int)(4.0 * sigma + 0.5);
@@ -97,7 +173,14 @@ int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
 // radius 0 (weight 1.0) is the identity: float32(u8) -> u8, so pages without blur (sigma_est <= 1,
 // mrc.py:309) ride along in the same launch.
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
-                          float *tmp, int tpitch, size_t tstride, int npages) {
+                          float *tmp, int tpitch, size_t tstride, int npages, int max_radius) {
+    if (max_radius <= GF_RMAX && w >= 2 * GF_RMAX) {
+        dim3 gridf(cdiv(w, GF_TW), cdiv(h, GF_TH), npages);
+        LAUNCH(ctx, s, "gauss_fused", 2.0 * w * h * npages,
+               hipLaunchKernelGGL(gauss_fused_kernel, gridf, dim3(256), 0, s, src.p, src.pitch, src.stride, dst.p, dst.pitch,
+                                  dst.stride, w, h, d_weights));
+        return 0;
+    }
     dim3 grid_v(cdiv(cdiv(w, 4), 256), h, npages);
     dim3 grid(cdiv(w, 256), h, npages);
     LAUNCH(ctx, s, "gauss_v", 5.0 * w * h * npages,
