@@ -111,39 +111,47 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 typedef unsigned __attribute__((aligned(1))) unsigned_u1;
 __device__ __forceinline__ unsigned ld_u32(const uint8_t *p) { return *reinterpret_cast<const unsigned_u1 *>(p); }
 
-// Horizontal pass: one lane per output pixel.  The coefficient table is stored transposed
-// (kkT[tap][xx]) so that a wave's coefficient loads are contiguous; the window's bytes come in
-// as (unaligned) dwords.  Taps beyond a window's length have zero coefficients, so the fixed
-// MAXK-tap loop needs no masking (the bytes it over-reads lie inside the row pitch / PAD).
+// Horizontal pass: one lane per output column, RH consecutive rows per lane (the fixed-point
+// coefficients of a column are loaded once and reused down the rows).  The coefficient table is
+// stored transposed (kkT[tap][xx]) so that a wave's coefficient loads are contiguous; the window's
+// bytes come in as (unaligned) dwords.  Taps beyond a window's length have zero coefficients, so
+// the fixed MAXK-tap loop needs no masking (the bytes it over-reads lie inside the row pitch / PAD).
+constexpr int RH = 8;
 template <int C, int MAXK>
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
                                                        uint8_t *dst, int dpitch, size_t dstride, int ow,
                                                        const int32_t *bounds, const int32_t *kkT) {
-    const int xx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int xx = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * RH;
     if (xx >= ow) return;
     src += (size_t)blockIdx.z * sstride;
     dst += (size_t)blockIdx.z * dstride;
     const int xmin = bounds[2 * xx];
-    const uint8_t *row = src + (size_t)y * spitch + (size_t)xmin * C;
+    int kv[MAXK];
+#pragma unroll
+    for (int x = 0; x < MAXK; x++) kv[x] = kkT[(size_t)x * ow + xx];
     constexpr int ND = (MAXK * C + 3) / 4;
-    unsigned v[ND];
+    const int ny = min(RH, h - y0);
+    for (int yy = 0; yy < ny; yy++) {
+        const int y = y0 + yy;
+        const uint8_t *row = src + (size_t)y * spitch + (size_t)xmin * C;
+        unsigned v[ND];
 #pragma unroll
-    for (int d = 0; d < ND; d++) v[d] = ld_u32(row + 4 * d);
-    int ss[C];
+        for (int d = 0; d < ND; d++) v[d] = ld_u32(row + 4 * d);
+        int ss[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) ss[ch] = 1 << 21;
+        for (int ch = 0; ch < C; ch++) ss[ch] = 1 << 21;
 #pragma unroll
-    for (int x = 0; x < MAXK; x++) {
-        const int kv = kkT[(size_t)x * ow + xx];
+        for (int x = 0; x < MAXK; x++) {
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-            const int j = x * C + ch;
-            ss[ch] += (int)((v[j >> 2] >> (8 * (j & 3))) & 0xffu) * kv;
+            for (int ch = 0; ch < C; ch++) {
+                const int j = x * C + ch;
+                ss[ch] += (int)((v[j >> 2] >> (8 * (j & 3))) & 0xffu) * kv[x];
+            }
         }
-    }
-    uint8_t *o = dst + (size_t)y * dpitch + (size_t)xx * C;
+        uint8_t *o = dst + (size_t)y * dpitch + (size_t)xx * C;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) o[ch] = clip8(ss[ch]);
+        for (int ch = 0; ch < C; ch++) o[ch] = clip8(ss[ch]);
+    }
 }
 
 // generic fallback (any ksize), row-major table
@@ -261,14 +269,17 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
         const dim3 grid(cdiv(p.ow, 256), ch_, npages);
         const double a = red ? 0.0 : alg;
         if (!p.khT_.empty()) {
-            if (c == 3)
-                LAUNCH(ctx, s, "thumb_resize_h", a,
-                       hipLaunchKernelGGL((resize_h_kernel<3, THUMB_MAXK>), grid, dim3(256), 0, s, cur.p, cur.pitch,
-                                          cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));
-            else
-                LAUNCH(ctx, s, "thumb_resize_h", a,
-                       hipLaunchKernelGGL((resize_h_kernel<1, THUMB_MAXK>), grid, dim3(256), 0, s, cur.p, cur.pitch,
-                                          cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));
+            const dim3 gridr(cdiv(p.ow, 256), cdiv(ch_, RH), npages);
+#define RSZ_H(CC, MK)                                                                                          \
+    LAUNCH(ctx, s, "thumb_resize_h", a,                                                                          \
+           hipLaunchKernelGGL((resize_h_kernel<CC, MK>), gridr, dim3(256), 0, s, cur.p, cur.pitch, cur.stride,   \
+                              ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT))
+            if (c == 3) {
+                if (p.ksh <= 9) RSZ_H(3, 9); else if (p.ksh <= 13) RSZ_H(3, 13); else RSZ_H(3, THUMB_MAXK);
+            } else {
+                if (p.ksh <= 9) RSZ_H(1, 9); else if (p.ksh <= 13) RSZ_H(1, 13); else RSZ_H(1, THUMB_MAXK);
+            }
+#undef RSZ_H
         } else {
             if (c == 3)
                 LAUNCH(ctx, s, "thumb_resize_h", a,
