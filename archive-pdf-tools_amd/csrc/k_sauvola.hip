@@ -81,15 +81,17 @@ __device__ __forceinline__ unsigned div_exact(unsigned N, unsigned c, float rc) 
 
 // the reference's decision (pyx:143-153) for one pixel; returns `form`.  mean and Q/count are the
 // truncated integer quotients (cdivision), everything after that is fp64 in the reference's order.
-__device__ __forceinline__ bool sauvola_form(unsigned mean_i, unsigned qd_i, unsigned px, double k, double km1, double k2) {
+__device__ __forceinline__ bool sauvola_form(unsigned mean_i, unsigned qd_i, unsigned px, bool kpos, double km1, double k2) {
+    const unsigned mm_i = __umul24(mean_i, mean_i);        // < 2^16
     const double mean = (double)mean_i;
-    const double mm = (double)(mean_i * mean_i);          // exact: < 2^16
-    const double variance = (double)qd_i - mm;            // exact integers in fp64
+    const double mm = (double)mm_i;                       // == mean*mean exactly
+    const double variance = (double)(int)(qd_i - mm_i);   // == (double)qd - mean*mean exactly (integers)
     const double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
     const double lhs = __dmul_rn(tmp, tmp);
     const double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
-    if (k >= 0) return (tmp <= 0) || (lhs <= rhs);
-    return (tmp <= 0) && (lhs >= rhs);
+    const bool neg = tmp <= 0;
+    // k >= 0: neg || lhs <= rhs;  k < 0: neg && lhs >= rhs   (pyx:146-151), branch-free
+    return kpos ? (neg || (lhs <= rhs)) : (neg && (lhs >= rhs));
 }
 
 // Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
@@ -101,8 +103,15 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
     constexpr int CW = 64 * K;
     constexpr int KD = K / 4;
     constexpr int PF = 4;                              // rows in flight
-    __shared__ __attribute__((aligned(16))) unsigned Es[CW];
-    __shared__ __attribute__((aligned(16))) unsigned Eq[CW];
+    // Prefix rows in LDS, transposed: strip column ci = K*t + i lives at [i][t + PL].  A wave's
+    // accesses for one pixel index i are then consecutive dwords (conflict-free); the natural
+    // [ci] order would put lanes 16 B apart = a 4-way bank conflict on every read.  PL lanes of
+    // slack on both sides: halo lanes evaluate the formula on out-of-strip indices instead of
+    // branching around it (their results are never stored).
+    constexpr int PL = 32, LS = 64 + 2 * PL;
+    __shared__ unsigned EsBuf[K * LS];
+    __shared__ unsigned EqBuf[K * LS];
+    auto pidx = [&](int ci) { const int c2 = ci + K * PL; return (c2 % K) * LS + c2 / K; };
 
     SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
     const int w = job.w, h = job.h;
@@ -152,51 +161,77 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             }
         }
     };
-    auto gload = [&](int yy, unsigned (&wv)[KD]) {       // masked row from global; rows outside the image are zero
-        if (yy >= 0 && yy < h) {
-            load_px<K>(src0 + (size_t)yy * job.src_pitch, wv);
+    // raw row from global memory (global, not flat, address space): the row index is clamped into
+    // the image and nothing touches the loaded registers here, so the load stays in flight until the
+    // row is USED several iterations later (masking at load time would put an s_waitcnt right here).
+    // Rows outside the image are skipped where they are used (wave-uniform tests).
+    typedef const unsigned __attribute__((address_space(1))) *gc_u32p;
+    auto gload = [&](int yy, unsigned (&wv)[KD]) {
+        const int yc = min(max(yy, 0), h - 1);
+        gc_u32p p = (gc_u32p)(src0 + (size_t)yc * job.src_pitch);
 #pragma unroll
-            for (int q = 0; q < KD; q++) wv[q] &= vmask[q];
-        } else {
+        for (int q = 0; q < KD; q++) wv[q] = p[q];
+    };
+    auto acc_row_m = [&](const unsigned (&wv)[KD], bool plus) {
+        unsigned m[KD];
 #pragma unroll
-            for (int q = 0; q < KD; q++) wv[q] = 0;
-        }
+        for (int q = 0; q < KD; q++) m[q] = wv[q] & vmask[q];
+        acc_row(m, plus);
     };
     // warm-up: rows [Y0-o, Y0+u-1] (clipped) enter the sums
     for (int yy = max(0, Y0 - o); yy < min(h, Y0 + u); yy++) {
         unsigned wv[KD];
         gload(yy, wv);
-        acc_row(wv, true);
+        acc_row_m(wv, true);
     }
     // three register queues, PF rows deep: entering rows y+u, leaving rows y-o, centre rows y.
     // Every address is known in advance, so the loads run PF rows ahead of their use and the
     // serial chain of a row never waits for memory (leaving / centre rows come back from L2/MALL).
-    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD];
+    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD], qm[PF][KD];
+    const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
+    const bool do_or = (P.flags & SAUVOLA_OR) != 0;
+    // OR mode (mask |= thr, mrc.py:329): the destination row is prefetched like the sources
+    typedef const unsigned __attribute__((address_space(1))) *gc_u32q;
+    const bool dst_al = ((reinterpret_cast<uintptr_t>(job.dst) + (intptr_t)c0) & 3u) == 0 && (job.dst_pitch & 3) == 0;
+    auto mload = [&](int yy, unsigned (&wv)[KD]) {
+        if (do_or && dst_al) {
+            const int yc = min(max(yy, 0), h - 1);
+            gc_u32q p = (gc_u32q)(job.dst + (size_t)yc * job.dst_pitch + c0);
+#pragma unroll
+            for (int q = 0; q < KD; q++) wv[q] = p[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < KD; q++) wv[q] = 0;
+        }
+    };
 #pragma unroll
     for (int d = 0; d < PF; d++) {
         gload(Y0 + u + d, qe[d]);
         gload(Y0 - o + d, ql[d]);
         gload(Y0 + d, qc[d]);
+        mload(Y0 + d, qm[d]);
     }
 
-    const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
-    const bool do_or = (P.flags & SAUVOLA_OR) != 0;
     unsigned ones_a = 0, ones_b = 0;
+    const bool kpos = P.k >= 0;
 
     for (int y = Y0; y < Y0 + rows; y++) {
         // ---- heads of the queues, then refill PF rows ahead ----
-        unsigned ev[KD], lv[KD], cv[KD];
+        unsigned ev[KD], lv[KD], cv[KD], mv[KD];
 #pragma unroll
-        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; }
+        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; mv[q] = qm[0][q]; }
 #pragma unroll
         for (int d = 0; d + 1 < PF; d++)
 #pragma unroll
-            for (int q = 0; q < KD; q++) { qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q]; }
+            for (int q = 0; q < KD; q++) {
+                qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q]; qm[d][q] = qm[d + 1][q];
+            }
         gload(y + u + PF, qe[PF - 1]);
         gload(y - o + PF, ql[PF - 1]);
         gload(y + PF, qc[PF - 1]);
-        acc_row(ev, true);                 // rows outside the image were loaded as zeros
-        acc_row(lv, false);
+        mload(y + PF, qm[PF - 1]);
+        if (y + u < h) acc_row_m(ev, true);
+        if (y - o >= 0) acc_row_m(lv, false);
         const int nrows = min(y + u, h - 1) - max(y - o, -1);
 
         // exclusive prefix over the strip's columns
@@ -208,11 +243,9 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         unsigned bq = wave_scan_incl(tq) - tq;
         lds_wave_sync();                   // previous row's LDS reads are done
 #pragma unroll
-        for (int i = 0; i < K; i += 4) {
-            uint4 a = make_uint4(bs + ps[i], bs + ps[i + 1], bs + ps[i + 2], bs + ps[i + 3]);
-            uint4 b = make_uint4(bq + pqx[i], bq + pqx[i + 1], bq + pqx[i + 2], bq + pqx[i + 3]);
-            *reinterpret_cast<uint4 *>(&Es[K * lane + i]) = a;
-            *reinterpret_cast<uint4 *>(&Eq[K * lane + i]) = b;
+        for (int i = 0; i < K; i++) {
+            EsBuf[i * LS + lane + PL] = bs + ps[i];
+            EqBuf[i * LS + lane + PL] = bq + pqx[i];
         }
         lds_wave_sync();
 
@@ -230,33 +263,33 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             const bool valid = (c >= X0) && (c < X0 + nout);
             any |= valid;
             all &= valid;
-            if (valid) {
-                const int ci = K * lane + i;
-                const unsigned S = Es[ci + r + 1] - Es[ci - l + 1];
-                const unsigned Q = Eq[ci + r + 1] - Eq[ci - l + 1];
-                unsigned count = ucount;
-                float rc = urc;
-                if (!full_cols) {
-                    const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
-                    count = (unsigned)(ncols * nrows);
-                    rc = __builtin_amdgcn_rcpf((float)count);
-                }
-                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
-                const unsigned mean_i = div_exact(S, count, rc);            // pyx:144 (cdivision)
-                const unsigned qd_i = div_exact(Q, count, rc);              // pyx:145
-                bool form = sauvola_form(mean_i, qd_i, px, P.k, P.km1, P.k2);
-                unsigned bit = (form ? 0u : 1u) ^ (invert ? 1u : 0u);   // pyx:153 (+ mrc.py:85)
-                outa[i / 4] |= bit << (8 * (i & 3));
-                ones_a += bit;
-                if (job.dst_inv) {
-                    // the same window on the image 255-p (mrc.py:224, 235)
-                    const unsigned Si = __umul24(255u, count) - S;
-                    const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
-                    bool fi = sauvola_form(div_exact(Si, count, rc), div_exact(Qi, count, rc), 255u - px, P.k, P.km1, P.k2);
-                    unsigned bi = (fi ? 0u : 1u) ^ (invert ? 1u : 0u);
-                    outb[i / 4] |= bi << (8 * (i & 3));
-                    ones_b += bi;
-                }
+            // evaluated for every column of the lane, valid or not (no divergent branch per pixel)
+            const int ci = K * lane + i;
+            const int ia = pidx(ci + r + 1), ib = pidx(ci - l + 1);
+            const unsigned S = EsBuf[ia] - EsBuf[ib];
+            const unsigned Q = EqBuf[ia] - EqBuf[ib];
+            unsigned count = ucount;
+            float rc = urc;
+            if (!full_cols) {
+                const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
+                count = (unsigned)max(ncols * nrows, 1);
+                rc = __builtin_amdgcn_rcpf((float)count);
+            }
+            const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
+            const unsigned mean_i = div_exact(S, count, rc);            // pyx:144 (cdivision)
+            const unsigned qd_i = div_exact(Q, count, rc);              // pyx:145
+            const bool form = sauvola_form(mean_i, qd_i, px, kpos, P.km1, P.k2);
+            const unsigned bit = valid ? ((form ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;   // pyx:153 (+ mrc.py:85)
+            outa[i / 4] |= bit << (8 * (i & 3));
+            ones_a += bit;
+            if (job.dst_inv) {
+                // the same window on the image 255-p (mrc.py:224, 235)
+                const unsigned Si = __umul24(255u, count) - S;
+                const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
+                const bool fi = sauvola_form(div_exact(Si, count, rc), div_exact(Qi, count, rc), 255u - px, kpos, P.km1, P.k2);
+                const unsigned bi = valid ? ((fi ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;
+                outb[i / 4] |= bi << (8 * (i & 3));
+                ones_b += bi;
             }
         }
         if (any) {
@@ -264,10 +297,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             const bool aligned = (reinterpret_cast<uintptr_t>(d) & 3u) == 0;
             if (all && aligned) {
 #pragma unroll
-                for (int q = 0; q < KD; q++) {
-                    unsigned *dp = reinterpret_cast<unsigned *>(d) + q;
-                    *dp = do_or ? (*dp | outa[q]) : outa[q];
-                }
+                for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(d)[q] = outa[q] | mv[q];   // mv = 0 unless OR mode
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) {
