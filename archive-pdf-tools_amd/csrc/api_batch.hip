@@ -388,6 +388,8 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     }
     Plane thr_src = b->gray;
     if (any_blur) {
+        if (gauss_uses_fused(w, h, max_radius))
+            for (int i = 0; i < N; i++) gauss_pad_weights(hg[i], max_radius);
         GaussW *dg = reinterpret_cast<GaussW *>(dctrl + L.gauss);
         HIP_TRY(hipMemcpyAsync(dg, hg, (size_t)N * sizeof(GaussW), hipMemcpyHostToDevice, s));
         TRY(launch_gaussian_batch(ctx, s, b->gray, b->blur.pl, w, h, dg, b->gtmp.as<float>(), b->gtmp_pitch,

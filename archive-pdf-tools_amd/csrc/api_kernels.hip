@@ -159,6 +159,7 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
     memset(&G, 0, sizeof(G));
     G.radius = radius;
     for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
+    if (gauss_uses_fused(w, h, radius)) gauss_pad_weights(G, radius);
     HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     Plane pa, pb;

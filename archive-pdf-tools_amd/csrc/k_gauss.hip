@@ -72,64 +72,86 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
 }
 
 // Fused separable blur for the radii the pipeline produces (sigma_est*0.1 -> radius <= 8): one
-// workgroup blurs a TW x TH tile.  Vertical pass straight from global memory (4 adjacent columns per
-// lane, aligned dword loads) into a float32 LDS tile that includes the 2r halo columns; horizontal
-// pass out of LDS (consecutive lanes -> consecutive floats, conflict-free); result bytes staged in
-// LDS and written as whole dwords.  Same arithmetic, same rounding points as the two-pass kernels
-// (float32 intermediate between the passes) -- the f32 scratch image never goes to HBM:
-// 2 B/px of traffic instead of 10.
-constexpr int GF_TW = 256, GF_TH = 32, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4;
+// workgroup blurs a 256 x 32 tile.  Vertical pass straight from global memory into a float32 LDS
+// tile that includes the 2R halo columns: lane = (4 adjacent columns, 8 consecutive rows), so the
+// 8+2R aligned dword loads a lane needs are all issued up front (one exposed memory latency per
+// lane, not per output).  Horizontal pass out of LDS (consecutive lanes -> consecutive floats,
+// conflict-free); result bytes staged in LDS and written as whole dwords.  Same arithmetic and
+// rounding points as the two-pass kernels (float32 intermediate between the passes), but the f32
+// scratch image never goes to HBM: 2 B/px of traffic instead of 10.
+// R is the largest radius in the batch; a page with a smaller radius has its table zero-padded to
+// R by the host: the extra outer taps add +0.0 first, which leaves every partial sum unchanged.
+constexpr int GF_TW = 256, GF_TH = 32, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 8, GF_THREADS = 320;
 
-__global__ __launch_bounds__(256) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride, uint8_t *dst,
-                                                          int dpitch, size_t dstride, int w, int h, const GaussW *Gs) {
+template <int R>
+__global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
+                                                                 uint8_t *dst, int dpitch, size_t dstride, int w, int h,
+                                                                 const GaussW *Gs) {
     __shared__ float tmpT[GF_TH][GF_LW];
     __shared__ __attribute__((aligned(4))) uint8_t outT[GF_TH][GF_TW];
     src += (size_t)blockIdx.z * sstride;
     dst += (size_t)blockIdx.z * dstride;
-    const GaussW &G = Gs[blockIdx.z];
-    const int r = G.radius;
+    const GaussW &G = Gs[blockIdx.z];              // padded to radius R by the host
     const int tid = threadIdx.x;
     const int X0 = blockIdx.x * GF_TW, Y0 = blockIdx.y * GF_TH;
-    const int Xa = max(0, X0 - r) & ~3;                       // first tile column, dword aligned
-    const int Xe = min(w, X0 + GF_TW + r);                    // one past the last needed column
-    const int ngroups = (Xe - Xa + 3) >> 2;
+    const int Xa = max(0, X0 - R) & ~3;                       // first tile column, dword aligned
+    const int Xe = min(w, X0 + GF_TW + R);                    // one past the last needed column
+    const int ngroups = (Xe - Xa + 3) >> 2;                   // <= 69
     const int nrows = min(GF_TH, h - Y0);
+    double wt[R + 1];                                          // wt[k] = weight of offset -(R-k) (and +(R-k))
+#pragma unroll
+    for (int k = 0; k <= R; k++) wt[k] = G.w[k];
     // ---- vertical pass: global -> float32 LDS tile ----
-    for (int item = tid; item < ngroups * nrows; item += 256) {
-        const int g = item % ngroups, ty = item / ngroups;
-        const int x = Xa + 4 * g, y = Y0 + ty;
-        auto ld4 = [&](int yy) { return *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x); };
-        const unsigned c = ld4(y);
-        const double wc = G.w[r];
-        double a0 = __dmul_rn((double)(c & 0xffu), wc), a1 = __dmul_rn((double)((c >> 8) & 0xffu), wc);
-        double a2 = __dmul_rn((double)((c >> 16) & 0xffu), wc), a3 = __dmul_rn((double)(c >> 24), wc);
-        for (int j = -r; j < 0; j++) {
-            const unsigned p = ld4(reflect_idx(y + j, h)), q = ld4(reflect_idx(y - j, h));
-            const double wj = G.w[r + j];
-            a0 = __dadd_rn(a0, __dmul_rn(__dadd_rn((double)(p & 0xffu), (double)(q & 0xffu)), wj));
-            a1 = __dadd_rn(a1, __dmul_rn(__dadd_rn((double)((p >> 8) & 0xffu), (double)((q >> 8) & 0xffu)), wj));
-            a2 = __dadd_rn(a2, __dmul_rn(__dadd_rn((double)((p >> 16) & 0xffu), (double)((q >> 16) & 0xffu)), wj));
-            a3 = __dadd_rn(a3, __dmul_rn(__dadd_rn((double)(p >> 24), (double)(q >> 24)), wj));
+    {
+        const int g = tid % 69, sgm = tid / 69;               // 69 column groups x 4 row segments (276 lanes)
+        if (g < ngroups && sgm < GF_TH / GF_SEG) {
+            const int x = Xa + 4 * g, y0 = Y0 + sgm * GF_SEG;
+            unsigned in[GF_SEG + 2 * R];
+#pragma unroll
+            for (int i = 0; i < GF_SEG + 2 * R; i++) {
+                const int yy = reflect_idx(min(y0 - R + i, h - 1 + R), h);   // rows past the tile's last row are unused
+                in[i] = *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x);
+            }
+#pragma unroll
+            for (int k = 0; k < GF_SEG; k++) {
+                if (y0 + k < h) {
+                    const unsigned c = in[k + R];
+                    double a0 = __dmul_rn((double)(c & 0xffu), wt[R]), a1 = __dmul_rn((double)((c >> 8) & 0xffu), wt[R]);
+                    double a2 = __dmul_rn((double)((c >> 16) & 0xffu), wt[R]), a3 = __dmul_rn((double)(c >> 24), wt[R]);
+#pragma unroll
+                    for (int j = R; j >= 1; j--) {            // offsets -j and +j, outermost first (scipy order)
+                        const unsigned p = in[k + R - j], q = in[k + R + j];
+                        const double wj = wt[R - j];
+                        // (double)a + (double)b of two bytes == (double)(a + b): one conversion
+                        a0 = __dadd_rn(a0, __dmul_rn((double)((p & 0xffu) + (q & 0xffu)), wj));
+                        a1 = __dadd_rn(a1, __dmul_rn((double)(((p >> 8) & 0xffu) + ((q >> 8) & 0xffu)), wj));
+                        a2 = __dadd_rn(a2, __dmul_rn((double)(((p >> 16) & 0xffu) + ((q >> 16) & 0xffu)), wj));
+                        a3 = __dadd_rn(a3, __dmul_rn((double)((p >> 24) + (q >> 24)), wj));
+                    }
+                    float *t = &tmpT[sgm * GF_SEG + k][4 * g];
+                    t[0] = (float)a0; t[1] = (float)a1; t[2] = (float)a2; t[3] = (float)a3;
+                }
+            }
         }
-        float *t = &tmpT[ty][4 * g];
-        t[0] = (float)a0; t[1] = (float)a1; t[2] = (float)a2; t[3] = (float)a3;
     }
     __syncthreads();
     // ---- horizontal pass: LDS -> result bytes in LDS ----
-    {
+    if (tid < GF_TW) {
         const int x = X0 + tid;
         if (x < w) {
-            const bool interior = (x - r >= 0) && (x + r < w);
+            const bool interior = (x - R >= 0) && (x + R < w);
             for (int ty = 0; ty < nrows; ty++) {
                 const float *row = &tmpT[ty][0] - Xa;             // row[c] = intermediate of image column c
-                double acc = __dmul_rn((double)row[x], G.w[r]);
+                double acc = __dmul_rn((double)row[x], wt[R]);
                 if (interior) {
-                    for (int j = -r; j < 0; j++)
-                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[x + j], (double)row[x - j]), G.w[r + j]));
+#pragma unroll
+                    for (int j = R; j >= 1; j--)
+                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[x - j], (double)row[x + j]), wt[R - j]));
                 } else {
-                    for (int j = -r; j < 0; j++)
-                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[reflect_idx(x + j, w)],
-                                                                 (double)row[reflect_idx(x - j, w)]), G.w[r + j]));
+#pragma unroll
+                    for (int j = R; j >= 1; j--)
+                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[reflect_idx(x - j, w)],
+                                                                 (double)row[reflect_idx(x + j, w)]), wt[R - j]));
                 }
                 outT[ty][tid] = (uint8_t)(float)acc;              // float32 result, astype(uint8) truncation
             }
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(256) void gauss_fused_kernel(const uint8_t *src, in
     }
     __syncthreads();
     // ---- store: whole dwords ----
-    for (int k = tid; k < nrows * (GF_TW / 4); k += 256) {
+    for (int k = tid; k < nrows * (GF_TW / 4); k += GF_THREADS) {
         const int ty = k / (GF_TW / 4), q = k % (GF_TW / 4);
         const int x = X0 + 4 * q, y = Y0 + ty;
         if (x >= w) continue;
@@ -145,6 +167,22 @@ __global__ __launch_bounds__(256) void gauss_fused_kernel(const uint8_t *src, in
         if (x + 4 <= w) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(&outT[ty][4 * q]);
         else for (int i = 0; x + i < w; i++) o[i] = outT[ty][4 * q + i];
     }
+}
+
+// true when launch_gaussian_batch will take the fused kernel, i.e. the tables must be padded
+bool gauss_uses_fused(int w, int h, int max_radius) {
+    return max_radius >= 1 && max_radius <= GF_RMAX && w >= 2 * GF_RMAX && h >= 2 * GF_RMAX;
+}
+
+// re-centre a radius-r table inside a radius-R one (zeros outside): taps added as +0.0
+void gauss_pad_weights(GaussW &g, int R) {
+    const int r = g.radius;
+    if (r >= R) return;
+    double t[2 * GMAXR + 1];
+    for (int i = 0; i < 2 * r + 1; i++) t[i] = g.w[i];
+    for (int i = 0; i < 2 * R + 1; i++) g.w[i] = 0.0;
+    for (int i = 0; i < 2 * r + 1; i++) g.w[i + (R - r)] = t[i];
+    g.radius = R;
 }
 
 int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
@@ -174,11 +212,17 @@ int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
 // mrc.py:309) ride along in the same launch.
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
                           float *tmp, int tpitch, size_t tstride, int npages, int max_radius) {
-    if (max_radius <= GF_RMAX && w >= 2 * GF_RMAX) {
+    if (max_radius >= 1 && max_radius <= GF_RMAX && w >= 2 * GF_RMAX && h >= 2 * GF_RMAX) {
+        // d_weights must be padded to max_radius (gauss_pad_weights)
         dim3 gridf(cdiv(w, GF_TW), cdiv(h, GF_TH), npages);
-        LAUNCH(ctx, s, "gauss_fused", 2.0 * w * h * npages,
-               hipLaunchKernelGGL(gauss_fused_kernel, gridf, dim3(256), 0, s, src.p, src.pitch, src.stride, dst.p, dst.pitch,
-                                  dst.stride, w, h, d_weights));
+#define GF_CASE(RR)                                                                                              \
+    case RR:                                                                                                     \
+        LAUNCH(ctx, s, "gauss_fused", 2.0 * w * h * npages,                                                      \
+               hipLaunchKernelGGL(gauss_fused_kernel<RR>, gridf, dim3(GF_THREADS), 0, s, src.p, src.pitch, src.stride, \
+                                  dst.p, dst.pitch, dst.stride, w, h, d_weights));                                \
+        break;
+        switch (max_radius) { GF_CASE(1) GF_CASE(2) GF_CASE(3) GF_CASE(4) GF_CASE(5) GF_CASE(6) GF_CASE(7) GF_CASE(8) }
+#undef GF_CASE
         return 0;
     }
     dim3 grid_v(cdiv(cdiv(w, 4), 256), h, npages);

@@ -236,7 +236,10 @@ int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_j
 constexpr int GMAXR = 60;
 struct GaussW { double w[2 * GMAXR + 1]; int radius; int pad_; };
 // d_weights: npages GaussW records (radius 0 = identity); tmp: page i at tmp + i*tstride floats
-// max_radius: the largest radius among the pages (host knows it): <= 8 takes the fused LDS kernel
+bool gauss_uses_fused(int w, int h, int max_radius);
+void gauss_pad_weights(GaussW &g, int R);
+// max_radius: the largest radius among the pages (host knows it): <= 8 takes the fused LDS kernel,
+// which expects every page's table padded to max_radius (gauss_pad_weights)
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
                           float *tmp, int tpitch, size_t tstride, int npages, int max_radius);
 // bits: page i at bits + i*bits_stride dwords
