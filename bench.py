@@ -88,12 +88,19 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # RCCL ("nccl") on the node; MRCHIP_DIST_BACKEND=gloo lets the launch path be exercised on a
+        # single-GPU box (two ranks cannot share one GPU under RCCL)
+        backend = os.environ.get('MRCHIP_DIST_BACKEND', 'nccl')
+        ndev = max(1, torch.cuda.device_count())
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank % ndev)
+            dist_.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ndev))
+        else:
+            dist_.init_process_group(backend)
         dist = dist_
 
     from mrchip import _lib, mrc
-    ctx = _lib.Context(local_rank if _lib.mrchip_visible_devices() > local_rank else 0)
+    ctx = _lib.Context(local_rank % max(1, _lib.mrchip_visible_devices()))
     lib = _lib.load()
     info = ctx.info()
 
@@ -134,8 +141,9 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if dist.get_backend() == 'nccl':
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(a.warmup):
