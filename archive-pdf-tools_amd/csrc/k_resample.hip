@@ -154,6 +154,79 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *src, int s
     }
 }
 
+// LDS-staged variant: the 256 output columns of a workgroup read overlapping windows (stride
+// scale*C bytes, window MAXK*C bytes), so the workgroup first copies the byte span it needs of each
+// of its RH rows into LDS with coalesced aligned dword loads (all issued up front), then every lane
+// assembles its window from aligned LDS dwords with v_alignbyte.  Used when the span fits LROW.
+constexpr int RH_LROW = 4096;       // bytes of LDS per staged row
+template <int C, int MAXK>
+__global__ __launch_bounds__(256) void resize_h_lds_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
+                                                           uint8_t *dst, int dpitch, size_t dstride, int ow,
+                                                           const int32_t *bounds, const int32_t *kkT) {
+    __shared__ unsigned stage[RH][RH_LROW / 4];
+    const int tid = threadIdx.x;
+    const int xx0 = blockIdx.x * 256, y0 = blockIdx.y * RH;
+    const int xx = xx0 + tid;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const int ny = min(RH, h - y0);
+    const int xlast = min(xx0 + 255, ow - 1);
+    const int first = bounds[2 * xx0];                                  // wave-uniform
+    const int span_bytes = (bounds[2 * xlast] + MAXK - first) * C;      // bytes needed from `first`
+    // ---- stage the rows ----
+    unsigned delta[RH];                                                 // byte phase of each row's staging origin
+#pragma unroll
+    for (int r = 0; r < RH; r++) {
+        const uint8_t *p = src + (size_t)min(y0 + r, h - 1) * spitch + (size_t)first * C;
+        delta[r] = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+    }
+    const int ndw = (span_bytes + 3 + 3) / 4 + 1;
+    for (int i = tid; i < ndw; i += 256) {
+        unsigned v[RH];
+#pragma unroll
+        for (int r = 0; r < RH; r++) {
+            const uint8_t *p = src + (size_t)min(y0 + r, h - 1) * spitch + (size_t)first * C - delta[r];
+            v[r] = reinterpret_cast<const unsigned *>(p)[i];
+        }
+#pragma unroll
+        for (int r = 0; r < RH; r++) stage[r][i] = v[r];
+    }
+    __syncthreads();
+    if (xx >= ow) return;
+    const int xmin = bounds[2 * xx];
+    int kv[MAXK];
+#pragma unroll
+    for (int x = 0; x < MAXK; x++) kv[x] = kkT[(size_t)x * ow + xx];
+    constexpr int ND = (MAXK * C + 3) / 4;
+#pragma unroll
+    for (int r = 0; r < RH; r++) {
+        if (r < ny) {
+            const unsigned off = (unsigned)(xmin - first) * C + delta[r];
+            const unsigned *lp = &stage[r][off >> 2];
+            const unsigned sh = off & 3u;
+            unsigned raw[ND + 1], v[ND];
+#pragma unroll
+            for (int d = 0; d <= ND; d++) raw[d] = lp[d];
+#pragma unroll
+            for (int d = 0; d < ND; d++) v[d] = __builtin_amdgcn_alignbyte(raw[d + 1], raw[d], sh);
+            int ss[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) ss[ch] = 1 << 21;
+#pragma unroll
+            for (int x = 0; x < MAXK; x++) {
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    const int j = x * C + ch;
+                    ss[ch] += (int)((v[j >> 2] >> (8 * (j & 3))) & 0xffu) * kv[x];
+                }
+            }
+            uint8_t *o = dst + (size_t)(y0 + r) * dpitch + (size_t)xx * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) o[ch] = clip8(ss[ch]);
+        }
+    }
+}
+
 // generic fallback (any ksize), row-major table
 template <int C>
 __global__ __launch_bounds__(256) void resize_h_generic_kernel(const uint8_t *src, int spitch, size_t sstride, int h,
@@ -270,10 +343,24 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
         const double a = red ? 0.0 : alg;
         if (!p.khT_.empty()) {
             const dim3 gridr(cdiv(p.ow, 256), cdiv(ch_, RH), npages);
+            // widest byte span a 256-column workgroup needs (host tables): LDS staging if it fits a row buffer
+            int span = 0;
+            for (int x0 = 0; x0 < p.ow; x0 += 256) {
+                const int xl = std::min(x0 + 255, p.ow - 1);
+                span = std::max(span, (p.bh_[2 * xl] + THUMB_MAXK - p.bh_[2 * x0]) * c);
+            }
+            const bool use_lds = span + 16 <= RH_LROW;
 #define RSZ_H(CC, MK)                                                                                          \
-    LAUNCH(ctx, s, "thumb_resize_h", a,                                                                          \
-           hipLaunchKernelGGL((resize_h_kernel<CC, MK>), gridr, dim3(256), 0, s, cur.p, cur.pitch, cur.stride,   \
-                              ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT))
+    do {                                                                                                        \
+        if (use_lds)                                                                                            \
+            LAUNCH(ctx, s, "thumb_resize_h", a,                                                                  \
+                   hipLaunchKernelGGL((resize_h_lds_kernel<CC, MK>), gridr, dim3(256), 0, s, cur.p, cur.pitch,   \
+                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));             \
+        else                                                                                                    \
+            LAUNCH(ctx, s, "thumb_resize_h", a,                                                                  \
+                   hipLaunchKernelGGL((resize_h_kernel<CC, MK>), gridr, dim3(256), 0, s, cur.p, cur.pitch,       \
+                                      cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));             \
+    } while (0)
             if (c == 3) {
                 if (p.ksh <= 9) RSZ_H(3, 9); else if (p.ksh <= 13) RSZ_H(3, 13); else RSZ_H(3, THUMB_MAXK);
             } else {
