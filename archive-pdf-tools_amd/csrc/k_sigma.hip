@@ -79,11 +79,31 @@ __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> 
         unsigned v = src[(size_t)yy * pitch + xx];
         return as_bool ? (T)(v ? 1 : 0) : (T)v;
     };
-    // axis 0 first (value t[k][xx]), then axis 1
-    auto tcol = [&](int xx) -> T {
-        return dwt_point<T>(F, h, 2 * k + 1, [&](int yy) { return px(yy, xx); });
-    };
-    T v = dwt_point<T>(F, w, 2 * m + 1, tcol);
+    T v;
+    const int iy = 2 * k + 1, ix = 2 * m + 1;
+    if (iy >= 3 && iy < h && ix >= 3 && ix < w) {
+        // interior coefficient: all 16 taps in range, straight-line code in the same order as the
+        // generic path (axis 0 first: t[c] = ((0 + f0*x[iy]) + f1*x[iy-1]) + ..., then axis 1)
+        T t[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int xx = ix - c;
+            T sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], px(iy - j, xx)));
+            t[c] = sum;
+        }
+        T sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], t[j]));
+        v = sum;
+    } else {
+        // border coefficient: PyWavelets' symmetric-extension order (axis 0 first, then axis 1)
+        auto tcol = [&](int xx) -> T {
+            return dwt_point<T>(F, h, iy, [&](int yy) { return px(yy, xx); });
+        };
+        v = dwt_point<T>(F, w, ix, tcol);
+    }
     dd[(size_t)k * w2 + m] = v;
 }
 
