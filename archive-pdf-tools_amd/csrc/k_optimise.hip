@@ -21,6 +21,8 @@
 // 2 jobs (fg, bg) per page, each on its own CU.
 //
 // Algorithmic bytes: (1 + 2C)*w*h per call (mask + img in, out).
+#include <cstdlib>
+
 #include "mrchip_internal.h"
 
 namespace mrchip {
@@ -312,7 +314,9 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
 // routed into the lanes with v_perm_b32, and the publish step is a straight ds_write_b64.
 // NCT: n_size as a compile-time constant (the reference's 3 and 10: every window loop unrolls and
 // every LDS access becomes `thread base + immediate offset`), or -1 for a run-time n.
-template <int C, int NH, int NCT>
+// DB: the two LDS rows are double-buffered (row y publishes into buffer y&1), which removes the
+// second barrier of a row; used when 2x the rows fit the 160 KiB of LDS.
+template <int C, int NH, int NCT, bool DB>
 __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem) {
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
@@ -328,12 +332,14 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int T = blockDim.x;
     const int t = threadIdx.x;
     const int x0 = t * P;
-    const int nent = T * P + 2 * npad;
+    const int wr = min(T * P, (w + 3) & ~3);      // columns that get an entry
+    const int nent = wr + 2 * npad;
     const int nelem = nent + nent / P + 1;
-    unsigned *firA = reinterpret_cast<unsigned *>(smem);
-    unsigned *iirA = firA + (size_t)nelem * EW;
-    for (int i = t; i < 2 * nelem * EW; i += T) firA[i] = 0;
+    unsigned *firA0 = reinterpret_cast<unsigned *>(smem);
+    unsigned *iirA0 = firA0 + (size_t)nelem * EW;
+    for (int i = t; i < (DB ? 4 : 2) * nelem * EW; i += T) firA0[i] = 0;
     __syncthreads();
+    unsigned *firA = firA0, *iirA = iirA0;
     // column c -> dword index of its entry (one pad entry per 4 columns: conflict-free lane stride).
     // With c = x0 + j and x0 = 4t: index = (5t + d + (d>>2)) * EW, d = j + n >= 0 -- `5t*EW` is the
     // thread's base, the rest folds to an immediate when n is a compile-time constant.
@@ -469,6 +475,11 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         const int ys = max(0, y - n);
 
         // ---- publish: the registers already hold the LDS entry format ----
+        if constexpr (DB) {
+            firA = firA0 + (size_t)(y & 1) * 2 * nelem * EW;
+            iirA = firA + (size_t)nelem * EW;
+        }
+        if (x0 < wr)
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int e = eidx(x0 + i);
@@ -570,7 +581,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         }
 #pragma unroll
         for (int q = 0; q < ND; q++) prev[q] = res[q];
-        lds_barrier();         // everyone is done reading the LDS rows
+        if constexpr (!DB) lds_barrier();   // everyone is done reading the LDS rows (DB: the next row uses the other buffer)
 
         r_enter = n_enter; r_leave = n_leave; r_cur = n_cur;
 #pragma unroll
@@ -578,16 +589,16 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     }
 }
 
-template <int C, int NH, int MAXT>
+template <int C, int NH, int MAXT, bool DB>
 __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const OptJob J = jobs[blockIdx.x];
     // wave-uniform dispatch on the job's n_size: the reference's two values get unrolled bodies
-    if (J.n == 3) optimise_packed_rows<C, NH, 3>(J, smem);            // fg, mrc.py:413/415
+    if (J.n == 3) optimise_packed_rows<C, NH, 3, DB>(J, smem);            // fg, mrc.py:413/415
     else if (J.n == 10) {
-        if constexpr (NH == 2) optimise_packed_rows<C, NH, 10>(J, smem);   // bg, mrc.py:447/449
-        else optimise_packed_rows<C, NH, -1>(J, smem);
-    } else optimise_packed_rows<C, NH, -1>(J, smem);
+        if constexpr (NH == 2) optimise_packed_rows<C, NH, 10, DB>(J, smem);   // bg, mrc.py:447/449
+        else optimise_packed_rows<C, NH, -1, DB>(J, smem);
+    } else optimise_packed_rows<C, NH, -1, DB>(J, smem);
 }
 
 struct OptGeom { int P, T; size_t lds; };
@@ -628,13 +639,23 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
         else if (g.P == 8) OPT_LAUNCH(CC, 8, 1024, NAME);                           \
         else OPT_LAUNCH(CC, 16, 1024, NAME);                                        \
     } while (0)
-#define OPT_PACKED(CC, NHH, MT, NAME)                                                                    \
+    // packed kernel: entries only for real columns; double-buffer the rows when twice that fits
+    const int wr = std::min(g.T * 4, (w + 3) & ~3);
+    const int pnent = wr + 2 * n_max;
+    const size_t plds1 = (size_t)(pnent + pnent / 4 + 1) * ((c == 3) ? 16 : 8);
+    // double buffering measured no faster than two barriers (9.45 vs 9.25 ms / 128 jobs): opt-in
+    static const bool want_db = getenv("MRCHIP_OPT_DB") != nullptr;
+    const bool db = want_db && 2 * plds1 <= 160 * 1024;
+    const size_t plds = db ? 2 * plds1 : plds1;
+#define OPT_PACKED2(CC, NHH, MT, DBB, NAME)                                                             \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_packed_kernel<CC, NHH, MT>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));           \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_packed_kernel<CC, NHH, MT, DBB>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));            \
         LAUNCH(ctx, s, NAME, alg,                                                                       \
-               hipLaunchKernelGGL((optimise_packed_kernel<CC, NHH, MT>), dim3(njobs), dim3(g.T), g.lds, s, d_jobs)); \
+               hipLaunchKernelGGL((optimise_packed_kernel<CC, NHH, MT, DBB>), dim3(njobs), dim3(g.T), plds, s, d_jobs)); \
     } while (0)
+#define OPT_PACKED(CC, NHH, MT, NAME)                                                                    \
+    do { if (db) OPT_PACKED2(CC, NHH, MT, true, NAME); else OPT_PACKED2(CC, NHH, MT, false, NAME); } while (0)
     if (g.P == 4 && n_max <= 11) {
         // 16-bit lane capacity: one FIR accumulator up to n=8, two halves up to n=11
         if (c == 3) {
@@ -647,6 +668,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
     } else if (c == 3) OPT_PICK(3, "optimise_rgb");
     else OPT_PICK(1, "optimise_gray");
 #undef OPT_PACKED
+#undef OPT_PACKED2
 #undef OPT_PICK
 #undef OPT_LAUNCH
     return 0;

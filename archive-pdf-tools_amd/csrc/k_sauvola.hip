@@ -389,7 +389,8 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
             return MRCHIP_E_ARG;
         }
     }
-    if (ww <= 120) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    static const int force_k = getenv("MRCHIP_SAUVOLA_K") ? atoi(getenv("MRCHIP_SAUVOLA_K")) : 0;   // tuning knob
+    if (ww <= 120 && force_k != 8) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     if (ww <= 360) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     return launch_k<16>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
 }
