@@ -537,9 +537,12 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             }
             const int cnt = fcnt + (y - ys) * (x - xs);
             const float rc = __builtin_amdgcn_rcpf((float)max(cnt, 1));   // 1 ulp: inside div_small's margin
+            const float hrc = 0.5f * rc;
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                const unsigned q = cnt > 0 ? div_small(fsum[c], rc) : 0u;
+                // (v + 0.5) * rc as one fma; cnt == 0 implies v == 0 and the quotient 0.5 truncates to 0,
+                // which is the reference's `else: 0` (pyx:266-269) without a select
+                const unsigned q = (unsigned)__builtin_fmaf((float)fsum[c], rc, hrc);
                 const int jb = i * C + c;
                 qd[jb >> 2] |= q << (8 * (jb & 3));
             }

@@ -362,9 +362,9 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
                                       cur.stride, ch_, o.p, o.pitch, o.stride, p.ow, d_bh, d_khT));             \
     } while (0)
             if (c == 3) {
-                if (p.ksh <= 9) RSZ_H(3, 9); else if (p.ksh <= 13) RSZ_H(3, 13); else RSZ_H(3, THUMB_MAXK);
+                if (p.ksh <= 9) RSZ_H(3, 9); else if (p.ksh <= 13) RSZ_H(3, 13); else if (p.ksh <= 16) RSZ_H(3, 16); else RSZ_H(3, THUMB_MAXK);
             } else {
-                if (p.ksh <= 9) RSZ_H(1, 9); else if (p.ksh <= 13) RSZ_H(1, 13); else RSZ_H(1, THUMB_MAXK);
+                if (p.ksh <= 9) RSZ_H(1, 9); else if (p.ksh <= 13) RSZ_H(1, 13); else if (p.ksh <= 16) RSZ_H(1, 16); else RSZ_H(1, THUMB_MAXK);
             }
 #undef RSZ_H
         } else {
