@@ -57,16 +57,15 @@ def cpu_baseline(sample_pages):
     O.lib()
     t0 = time.time()
     n = 0
-    for img, hocr, _ in sample_pages:
+    while time.time() - t0 < 12.0:                  # ~12-15 s of CPU work, cycling the distinct pages
+        img, hocr, _ = sample_pages[n % len(sample_pages)]
         g = O.create_mrc_hocr_components(img, hocr, dpi=None, bg_downsample=BG_DOWNSAMPLE, denoise_mask='fast')
         for _ in g:
             pass
         n += 1
-        if time.time() - t0 > 25:
-            break
     dt = time.time() - t0
     return {'value': round(n / dt, 4), 'unit': 'pages/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d of the same 4000x3000 RGB pages through oracle/mrc_oracle.c (-O3, 1 thread), %.1f s'
+            'sample': '%d decompositions of the same 4000x3000 RGB pages through oracle/mrc_oracle.c (-O3, 1 thread), %.1f s'
                       % (n, dt), 'host_cpus': os.cpu_count()}
 
 
