@@ -49,3 +49,24 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors='replace').read()
                 assert 'mrc_oracle' not in text and 'oracle/' not in text.replace('# oracle/', ''), \
                     '%s references the oracle' % os.path.join(dirpath, f)
+
+
+def test_thumbnail_size_rule_matches_oracle_and_pillow():
+    """mrchip_thumbnail_size is host logic (Pillow's Image.thumbnail size rule): check it on the CPU
+    against the oracle and against Pillow itself."""
+    import ctypes as C
+    import mrc_oracle as O
+    from PIL import Image
+    lib = _lib.load()
+    for (w, h) in [(800, 600), (4000, 3000), (3300, 4600), (8000, 6000), (1333, 999), (17, 900), (900, 17), (5, 5), (1, 1)]:
+        for f in (1, 2, 3, 4, 5, 7, 10, 33):
+            rw, rh = int(w / f), int(h / f)
+            if rw <= 0 or rh <= 0:
+                continue
+            ow, oh = C.c_int(), C.c_int()
+            changed = lib.mrchip_thumbnail_size(w, h, rw, rh, C.byref(ow), C.byref(oh))
+            assert (ow.value, oh.value, bool(changed)) == O.thumbnail_size(w, h, rw, rh), (w, h, f)
+            im = Image.new('L', (w, h))
+            im.thumbnail((rw, rh))
+            assert im.size == (ow.value, oh.value), (w, h, f, im.size)
+    assert lib.mrchip_thumbnail_size(800, 600, 266, 200, C.byref(ow), C.byref(oh)) == 1 and (ow.value, oh.value) == (266, 200)

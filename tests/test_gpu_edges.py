@@ -1,0 +1,100 @@
+"""GPU parity on edge cases: tiny pages, pages smaller than the window, widths that are not a
+multiple of any vector width, empty / degenerate hOCR, non-contiguous and PIL inputs, API misuse."""
+import numpy as np
+import pytest
+
+import mrc_oracle as O
+from mrchip import _lib, mrc, optimiser, sauvola, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def both(img, hocr, **kw):
+    g = mrc.create_mrc_hocr_components(img, hocr, **kw)
+    got = [next(g).copy(), next(g), next(g)]
+    e = O.create_mrc_hocr_components(img, hocr, **kw)
+    exp = [next(e).copy(), next(e), next(e)]
+    return got, exp
+
+
+@pytest.mark.parametrize('w,h,ch', [(1, 1, 1), (1, 1, 3), (2, 3, 3), (5, 5, 1), (7, 4, 3), (13, 31, 3), (51, 51, 1),
+                                    (64, 3, 3), (3, 64, 1), (255, 17, 3), (257, 65, 3), (1021, 9, 1)])
+def test_tiny_and_odd_pages(w, h, ch):
+    rng = np.random.RandomState(w * 131 + h)
+    img = rng.randint(0, 256, (h, w) if ch == 1 else (h, w, 3)).astype(np.uint8)
+    got, exp = both(img, [], denoise_mask='fast', bg_downsample=3, fg_downsample=2)
+    for a, b in zip(got, exp):
+        assert a.shape == b.shape and np.array_equal(a, b), (w, h, ch)
+
+
+def test_boxes_touching_borders_and_degenerate():
+    img, _ = synth.synth_page(300, 200, 1, seed=3, noise_sigma=4.0, line_div=10)
+    hocr = [{'lines': [
+        {'bbox': [0, 0, 300, 200], 'words': [{'text': 'a', 'confidence': 90}]},          # the whole page
+        {'bbox': [0, 0, 1, 1], 'words': [{'text': 'a', 'confidence': 90}]},              # 1x1
+        {'bbox': [299, 199, 300, 200], 'words': [{'text': 'a', 'confidence': 90}]},      # last pixel
+        {'bbox': [10, 10, 10, 50], 'words': [{'text': 'a', 'confidence': 90}]},          # zero width: skipped
+        {'bbox': [50, 60, 40, 70], 'words': [{'text': 'a', 'confidence': 90}]},          # inverted: skipped + message
+        {'bbox': [-5, 10, 40, 30], 'words': [{'text': 'a', 'confidence': 90}]},          # outside: skipped + message
+        {'bbox': [10.9, 20.2, 290.7, 45.9], 'words': [{'text': 'a', 'confidence': 19.9}]},   # low confidence
+        {'bbox': [10.9, 50.2, 290.7, 75.9], 'words': []},                                 # no words -> conf 0
+        {'bbox': [10.9, 80.2, 290.7, 120.9], 'words': [{'text': 'x', 'confidence': 20}]},  # float coords truncated
+        {'bbox': [100, 90, 250, 140], 'words': [{'text': 'x', 'confidence': 50}]},        # overlaps the previous
+    ]}]
+    got, exp = both(img, hocr, denoise_mask='fast', bg_downsample=2)
+    for a, b in zip(got, exp):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    got, exp = both(np.ascontiguousarray(img[::2, ::2]), hocr, downsample=2, denoise_mask='none')
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
+
+
+def test_non_contiguous_and_pil_modes():
+    from PIL import Image
+    base, hocr = synth.synth_page(260, 180, 3, seed=9, line_div=9)
+    view = base[::-1, ::-1]                                    # negative strides
+    a = [x for x in mrc.create_mrc_hocr_components(view, [], denoise_mask='fast')]
+    b = [x for x in O.create_mrc_hocr_components(np.ascontiguousarray(view), [], denoise_mask='fast')]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    pal = Image.fromarray(base).convert('P')                   # mapped image -> RGB (mrc.py:401-404)
+    rgb = np.array(pal.convert('RGB'))
+    a = [x for x in mrc.create_mrc_hocr_components(pal, [], denoise_mask='fast')]
+    b = [x for x in O.create_mrc_hocr_components(rgb, [], denoise_mask='fast')]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # threshold_image on a strided crop, like mrc.py:223-230
+    gray = O.luma601(base)
+    crop = gray[20:90, 33:201]
+    assert np.array_equal(mrc.threshold_image(crop, 150, 0.1), O.threshold_image(np.ascontiguousarray(crop), 150, 0.1))
+
+
+def test_kernel_entry_points_reject_bad_arguments():
+    with pytest.raises(ValueError):
+        sauvola.binarise_sauvola(np.zeros((4, 4), np.uint8), np.zeros(16, np.uint8), 4, 4, 3, 3, 0.3, 128)   # 2-D in_arr
+    with pytest.raises(ValueError):
+        sauvola.binarise_sauvola(np.zeros(16, np.float32), np.zeros(16, np.uint8), 4, 4, 3, 3, 0.3, 128)     # dtype
+    with pytest.raises(ValueError):
+        optimiser.optimise_rgb2(np.zeros((4, 4), bool), np.zeros((4, 4), np.uint8), 4, 4, 3)                 # ndim
+    with pytest.raises(_lib.MrchipError):
+        optimiser.optimise_gray2(np.zeros((4, 4), bool), np.zeros((4, 4), np.uint8), 4, 4, 99)               # n > 32
+    lib, ctx = _lib.load(), _lib.default_context()
+    pg = lib.mrchip_page_create(ctx.handle, 16, 16, 1)
+    assert pg
+    import ctypes as C
+    assert lib.mrchip_page_sigma(pg, C.byref(C.c_double())) == -5                 # MRCHIP_E_STATE: nothing uploaded
+    assert lib.mrchip_page_layer(pg, 0, 0.0, None, None, None) == -5
+    assert b'before' in lib.mrchip_last_error()
+    lib.mrchip_page_destroy(pg)
+    assert not lib.mrchip_page_create(ctx.handle, 0, 16, 1)
+    assert not lib.mrchip_page_create(ctx.handle, 16, 16, 4)
+
+
+def test_optimise_generic_path_and_large_n():
+    rng = np.random.RandomState(4)
+    for (h, w, n) in [(60, 300, 15), (40, 257, 32), (30, 100, 12)]:     # n > 11: the unpacked kernel
+        m = rng.rand(h, w) < 0.2
+        c = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        assert np.array_equal(optimiser.optimise_rgb2(m, c, w, h, n), O.optimise_rgb2(m, c, w, h, n)), n
+        assert np.array_equal(optimiser.optimise_gray2(m, g, w, h, n), O.optimise_gray2(m, g, w, h, n)), n
