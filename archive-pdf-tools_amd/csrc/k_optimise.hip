@@ -493,6 +493,14 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         }
         lds_barrier();
 
+        // Only pixels with mask==0 get a quotient.  When every pixel of this wave's 256 columns is masked
+        // in this row (most of the bg layer: the inverted mask is set wherever there is no ink) the
+        // horizontal windows and the divisions are skipped for the whole wave; the row is a copy.
+        const unsigned on_cur = on_bytes(r_cur.m[0]);
+        unsigned qd[ND];
+#pragma unroll
+        for (int q = 0; q < ND; q++) qd[q] = 0;
+        if (__any(on_cur != colm)) {
         // ---- horizontal windows of pixel x0: FIR [x0-n, x0+n) as NH packed halves, IIR [x0-n, x0) ----
         Ent aL, aR, aI;
 #pragma unroll
@@ -513,9 +521,6 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             }
         }
 
-        unsigned qd[ND];
-#pragma unroll
-        for (int q = 0; q < ND; q++) qd[q] = 0;
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int x = x0 + i;
@@ -556,10 +561,11 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 eadd(aI, iirE[i]); esub(aI, lds_ld(iirA, x - n));
             }
         }
+        }
         // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient
         unsigned res[ND];
         {
-            const unsigned on = on_bytes(r_cur.m[0]);
+            const unsigned on = on_cur;
             if constexpr (C == 3) {
                 const unsigned e0 = __builtin_amdgcn_perm(0u, on, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on, 0x02020101u),
                                e2 = __builtin_amdgcn_perm(0u, on, 0x03030302u);
