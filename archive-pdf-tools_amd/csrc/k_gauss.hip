@@ -87,8 +87,7 @@ template <int R>
 __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
                                                                  uint8_t *dst, int dpitch, size_t dstride, int w, int h,
                                                                  const GaussW *Gs) {
-    __shared__ float tmpT[GF_TH][GF_LW];
-    __shared__ __attribute__((aligned(4))) uint8_t outT[GF_TH][GF_TW];
+    __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];   // GF_LW % 4 == 0: rows stay 16-B aligned
     src += (size_t)blockIdx.z * sstride;
     dst += (size_t)blockIdx.z * dstride;
     const GaussW &G = Gs[blockIdx.z];              // padded to radius R by the host
@@ -128,44 +127,51 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
                         a2 = __dadd_rn(a2, __dmul_rn((double)(((p >> 16) & 0xffu) + ((q >> 16) & 0xffu)), wj));
                         a3 = __dadd_rn(a3, __dmul_rn((double)((p >> 24) + (q >> 24)), wj));
                     }
-                    float *t = &tmpT[sgm * GF_SEG + k][4 * g];
-                    t[0] = (float)a0; t[1] = (float)a1; t[2] = (float)a2; t[3] = (float)a3;
+                    // one 16-byte LDS store (four dword stores 16 B apart per lane would be a 4-way bank conflict)
+                    *reinterpret_cast<float4 *>(&tmpT[sgm * GF_SEG + k][4 * g]) = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
                 }
             }
         }
     }
     __syncthreads();
-    // ---- horizontal pass: LDS -> result bytes in LDS ----
+    // ---- horizontal pass: LDS -> global.  lane = (4 adjacent columns, 8 consecutive rows): the 4 + 2R floats a lane
+    // needs come in as 16-byte LDS reads and are widened to double once each; the four result bytes leave as one dword
     if (tid < GF_TW) {
-        const int x = X0 + tid;
-        if (x < w) {
-            const bool interior = (x - R >= 0) && (x + R < w);
-            for (int ty = 0; ty < nrows; ty++) {
+        constexpr int RP = (R <= 4) ? 4 : 8;                      // halo rounded up to whole float4s
+        const int q = tid & 63, sgm = tid >> 6;
+        const int x0 = X0 + 4 * q;
+        if (x0 < w) {
+            const bool interior = (x0 - R >= 0) && (x0 + 3 + R < w);
+#pragma unroll 2
+            for (int k = 0; k < GF_SEG; k++) {
+                const int ty = sgm * GF_SEG + k;
+                if (ty >= nrows) break;
                 const float *row = &tmpT[ty][0] - Xa;             // row[c] = intermediate of image column c
-                double acc = __dmul_rn((double)row[x], wt[R]);
+                double v[4 + 2 * RP];                             // v[i] = column x0 - RP + i
                 if (interior) {
 #pragma unroll
-                    for (int j = R; j >= 1; j--)
-                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[x - j], (double)row[x + j]), wt[R - j]));
+                    for (int i = 0; i < (4 + 2 * RP) / 4; i++) {
+                        const float4 f = *reinterpret_cast<const float4 *>(row + x0 - RP + 4 * i);
+                        v[4 * i] = (double)f.x; v[4 * i + 1] = (double)f.y; v[4 * i + 2] = (double)f.z; v[4 * i + 3] = (double)f.w;
+                    }
                 } else {
 #pragma unroll
-                    for (int j = R; j >= 1; j--)
-                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[reflect_idx(x - j, w)],
-                                                                 (double)row[reflect_idx(x + j, w)]), wt[R - j]));
+                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = (double)row[reflect_idx(x0 - RP + i, w)];
                 }
-                outT[ty][tid] = (uint8_t)(float)acc;              // float32 result, astype(uint8) truncation
+                unsigned packed = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    double acc = __dmul_rn(v[RP + e], wt[R]);
+#pragma unroll
+                    for (int j = R; j >= 1; j--)
+                        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(v[RP + e - j], v[RP + e + j]), wt[R - j]));
+                    packed |= (unsigned)(uint8_t)(float)acc << (8 * e);   // float32 result, astype(uint8) truncation
+                }
+                uint8_t *o = dst + (size_t)(Y0 + ty) * dpitch + x0;
+                if (x0 + 4 <= w) *reinterpret_cast<unsigned *>(o) = packed;
+                else for (int i = 0; x0 + i < w; i++) o[i] = (uint8_t)(packed >> (8 * i));
             }
         }
-    }
-    __syncthreads();
-    // ---- store: whole dwords ----
-    for (int k = tid; k < nrows * (GF_TW / 4); k += GF_THREADS) {
-        const int ty = k / (GF_TW / 4), q = k % (GF_TW / 4);
-        const int x = X0 + 4 * q, y = Y0 + ty;
-        if (x >= w) continue;
-        uint8_t *o = dst + (size_t)y * dpitch + x;
-        if (x + 4 <= w) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(&outT[ty][4 * q]);
-        else for (int i = 0; x + i < w; i++) o[i] = outT[ty][4 * q + i];
     }
 }
 

@@ -98,3 +98,20 @@ def test_optimise_generic_path_and_large_n():
         g = rng.randint(0, 256, (h, w)).astype(np.uint8)
         assert np.array_equal(optimiser.optimise_rgb2(m, c, w, h, n), O.optimise_rgb2(m, c, w, h, n)), n
         assert np.array_equal(optimiser.optimise_gray2(m, g, w, h, n), O.optimise_gray2(m, g, w, h, n)), n
+
+
+@pytest.mark.parametrize('radius', [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_gaussian_every_fused_radius_and_ragged_widths(radius):
+    """scipy radius = int(4 sigma + 0.5); radii 1..8 take the fused tile kernel (halo of one or two float4s per
+    lane), 9 the two-pass fallback.  Widths straddle the 256-column tile and the 4-column lane group."""
+    lib, ctx = _lib.load(), _lib.default_context()
+    sig = (radius - 0.5) / 4.0 + 0.06
+    wts, r = mrc.gaussian_weights(sig)
+    assert r == radius
+    rng = np.random.RandomState(radius)
+    for (h, w) in [(33, 16), (40, 255), (65, 257), (31, 259), (70, 513), (16, 1001)]:
+        g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), r))
+        exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
+        assert np.array_equal(out, exp), (radius, h, w)
