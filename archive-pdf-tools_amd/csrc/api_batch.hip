@@ -437,14 +437,11 @@ static int prepare_thumb(mrchip_batch *b, int Lr, double downsample, int *too_sm
             HIP_TRY(hipStreamSynchronize(b->s));
             TRY(b->small[Lr].alloc(ctx, N, p.ow * c, p.oh, false));
             TRY(b->sc1[Lr].alloc(ctx, N, p.rw * c, p.rh, false));
-            TRY(b->sc2[Lr].alloc(ctx, N, p.ow * c, p.rh, false));
+            int s2w, s2h;
+            ThumbPlan_scratch2_dims(p, &s2w, &s2h);
+            TRY(b->sc2[Lr].alloc(ctx, N, s2w, s2h, false));
             TRY(b->tables[Lr].alloc(ctx, ThumbPlan_table_bytes(p)));
-            int32_t *d = b->tables[Lr].as<int32_t>();
-            HIP_TRY(hipMemcpy(d, p.bh_.data(), p.bh_.size() * 4, hipMemcpyHostToDevice)); d += p.bh_.size();
-            HIP_TRY(hipMemcpy(d, p.kh_.data(), p.kh_.size() * 4, hipMemcpyHostToDevice)); d += p.kh_.size();
-            HIP_TRY(hipMemcpy(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice)); d += p.bv_.size();
-            HIP_TRY(hipMemcpy(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice)); d += p.kv_.size();
-            if (!p.khT_.empty()) HIP_TRY(hipMemcpy(d, p.khT_.data(), p.khT_.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->tables[Lr].p, p.blob_.data(), p.blob_.size(), hipMemcpyHostToDevice));
         }
     }
     if (p.changed) { b->layer_w[Lr] = p.ow; b->layer_h[Lr] = p.oh; b->layer_small[Lr] = 1; }
@@ -484,7 +481,7 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
         if (b->layer_small[Lr])
-            TRY(launch_thumbnail_plan(ctx, s, b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl, b->tables[Lr].as<int32_t>(),
+            TRY(launch_thumbnail_plan(ctx, s, b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl, b->tables[Lr].p,
                                       b->sc1[Lr].pl, b->sc2[Lr].pl, N));
         b->layer_done[Lr] = 1;
     }

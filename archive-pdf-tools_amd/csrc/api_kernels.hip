@@ -192,21 +192,18 @@ MRCHIP_EXPORT int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, in
     TRY(src.alloc(ctx, w, h, c));
     TRY(dst.alloc(ctx, (size_t)p.ow * p.oh * c + 256));
     TRY(s1.alloc(ctx, (size_t)p.rw * p.rh * c + 256));
-    TRY(s2.alloc(ctx, (size_t)p.ow * p.rh * c + 256));
+    int s2w, s2h;
+    ThumbPlan_scratch2_dims(p, &s2w, &s2h);
+    TRY(s2.alloc(ctx, (size_t)s2w * s2h + 256));
     TRY(tab.alloc(ctx, ThumbPlan_table_bytes(p)));
-    int32_t *d = tab.as<int32_t>();
-    HIP_TRY(hipMemcpyAsync(d, p.bh_.data(), p.bh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bh_.size();
-    HIP_TRY(hipMemcpyAsync(d, p.kh_.data(), p.kh_.size() * 4, hipMemcpyHostToDevice, s)); d += p.kh_.size();
-    HIP_TRY(hipMemcpyAsync(d, p.bv_.data(), p.bv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.bv_.size();
-    HIP_TRY(hipMemcpyAsync(d, p.kv_.data(), p.kv_.size() * 4, hipMemcpyHostToDevice, s)); d += p.kv_.size();
-    if (!p.khT_.empty()) HIP_TRY(hipMemcpyAsync(d, p.khT_.data(), p.khT_.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tab.p, p.blob_.data(), p.blob_.size(), hipMemcpyHostToDevice, s));
     TRY(upload_2d(s, src.p, src.pitch, in, w * c, w * c, h));
     Plane psrc, pdst, p1, p2;
     psrc.p = src.p; psrc.pitch = src.pitch;
     pdst.p = dst.as<uint8_t>(); pdst.pitch = p.ow * c;
     p1.p = s1.as<uint8_t>(); p1.pitch = p.rw * c;
-    p2.p = s2.as<uint8_t>(); p2.pitch = p.ow * c;
-    TRY(launch_thumbnail_plan(ctx, s, p, psrc, pdst, tab.as<int32_t>(), p1, p2, 1));
+    p2.p = s2.as<uint8_t>(); p2.pitch = s2w;
+    TRY(launch_thumbnail_plan(ctx, s, p, psrc, pdst, tab.p, p1, p2, 1));
     HIP_TRY(hipMemcpyAsync(out, dst.p, (size_t)p.ow * p.oh * c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

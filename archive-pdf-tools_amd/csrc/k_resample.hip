@@ -4,7 +4,9 @@
 // row a11).  The size rule and the coefficient tables are host logic (double precision,
 // exactly as Pillow computes them); the pixel passes are integer HIP kernels.
 // Algorithmic bytes: C*P*(1 + 1/f^2) per layer.
+#include <climits>
 #include <cmath>
+#include <cstring>
 
 #include "mrchip_internal.h"
 
@@ -281,6 +283,196 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *src, int s
     }
 }
 
+// ---- matrix-core resize pass ----------------------------------------------------------
+// A bicubic pass is out[line][n] = clip8((2^21 + sum_k px[line][k] * coef[k][n]) >> 22): the
+// product of the pixel lines (M x K, uint8) with a banded coefficient matrix (K x N, 22-bit
+// fixed point), i.e. real multiply-accumulate work (13-17 taps per output byte) and the one stage
+// of this path that belongs on the MFMA units.  v_mfma_i32_16x16x64_i8 multiplies signed bytes
+// exactly into int32, so
+//   * the pixels go in as px - 128 (one XOR 0x80 per dword); the constant 128 * sum(coef) + 2^21
+//     comes back through `bias`,
+//   * each coefficient is split into three balanced base-256 digits d0 + 256 d1 + 65536 d2
+//     (|coef| < 2^23), one MFMA per digit, recombined with shifts (mod 2^32; the true sum fits).
+// One wave owns a tile of 16 outputs (its B operand -- KB blocks of 64 input bytes x 3 digits --
+// stays in registers) and walks down groups of 16 lines: per group KB 16-byte loads per lane
+// (lane = line l&15, bytes (l>>4)*16.. of the block), 3*KB MFMAs, and the epilogue.  The MFMA
+// result has lane = (output l&15, lines (l>>4)*4..+3), so the four result bytes of a lane are
+// adjacent in the TRANSPOSED output: the horizontal pass writes its result transposed
+// ([output byte][row]) as whole dwords, which makes the vertical pass the same kernel again
+// (its K runs along the rows) and puts the final image back in row-major order.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef v4i v4i_u1 __attribute__((aligned(1)));
+
+// Memory side of the pass.  The MFMA operand layout (lane = line, 16 consecutive K bytes) is the
+// worst case for the vector memory path -- every lane of a load in a different row, 64 cache
+// lines per instruction -- and so is the result layout for the stores.  Both go through a small
+// wave-private LDS panel instead (no workgroup barrier: a wave's LDS operations execute in order):
+//   in : lanes run along K first (KB*4 chunks of 16 bytes per line), i.e. each load instruction
+//        covers 64/(KB*4) lines x KB*64 contiguous bytes; the panel rows are 16-byte aligned
+//        whatever kbase is, so the operand reads are aligned ds_read_b128
+//   out: the dwords of four line groups are collected per output and leave as 16-byte stores,
+//        64 contiguous bytes per output and quad.
+template <int KB, int WPB>
+__global__ __launch_bounds__(64 * WPB) void resize_mm_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
+                                                        uint8_t *dst, int dpitch, size_t dstride, int nout, int ntiles,
+                                                        const int32_t *kbase, const int32_t *bias, const v4i *btab,
+                                                        int quads_per_wave, int pad_ok, int gx, int gy, int gz) {
+    // XCD-aware work order: workgroup L runs on XCD L % 8 (round-robin dispatch).  Neighbouring tiles
+    // read overlapping bytes of the same lines, so each XCD (own L2) takes one contiguous range of the
+    // x-fastest work list instead of every eighth item.
+    const int total = gx * gy * gz, per = (total + 7) >> 3;
+    const int V = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (V >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int bx = V % gx, by = (V / gx) % gy, bz = V / (gx * gy);
+    constexpr int CPL = KB * 4;                   // 16-byte chunks per line
+    constexpr int LPI = 64 / CPL;                 // lines per load instruction
+    constexpr int LSTR = KB * 64 + 16;            // panel row stride: 8 consecutive rows hit 8 distinct 16-byte bank groups
+    constexpr int OSTR = 80;
+    __shared__ __attribute__((aligned(16))) unsigned char inP[WPB][16 * LSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char outP[WPB][16 * OSTR];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = bx * WPB + wv;
+    if (tile >= ntiles) return;
+    src += (size_t)bz * sstride;
+    dst += (size_t)bz * dstride;
+    const int nn = lane & 15, kq = lane >> 4;
+    v4i B[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) B[kb][d] = btab[((size_t)(tile * KB + kb) * 3 + d) * 64 + lane];
+    const int bs = bias[tile * 16 + nn];                  // padded to 16 * ntiles entries
+    const int kb0 = kbase[tile];
+    const int nquads = (nlines + 63) >> 6;
+    const int q0 = by * quads_per_wave, q1 = min(nquads, q0 + quads_per_wave);
+    if (q0 >= q1) return;
+    unsigned char *ip = inP[wv], *op = outP[wv];
+    const int ld_line = lane / CPL, ld_chunk = lane % CPL;
+
+    auto gload = [&](int g, v4i (&A)[KB]) {
+#pragma unroll
+        for (int r = 0; r < KB; r++) {
+            const int line = min(g * 16 + ld_line + r * LPI, nlines - 1);   // past the end: repeat the last line (never stored)
+            A[r] = *reinterpret_cast<const v4i_u1 *>(src + (size_t)line * spitch + kb0 + ld_chunk * 16);
+        }
+    };
+    v4i stage[2][KB];                                     // two groups of lines in flight
+    const int g_end = q1 * 4;
+    gload(q0 * 4, stage[0]);
+    gload(min(q0 * 4 + 1, g_end - 1), stage[1]);
+    for (int q = q0; q < q1; q++) {
+#pragma unroll
+    for (int gi = 0; gi < 4; gi++) {
+        const int g = q * 4 + gi;
+        // this group's lines: registers -> panel (px - 128 on the way)
+#pragma unroll
+        for (int r = 0; r < KB; r++)
+            *reinterpret_cast<v4i *>(ip + (ld_line + r * LPI) * LSTR + ld_chunk * 16) = stage[gi & 1][r] ^ (int)0x80808080;
+        gload(min(g + 2, g_end - 1), stage[gi & 1]);      // lines of group g+2 are in flight during the MFMAs
+        lds_wave_sync();
+        v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+            const v4i x = *reinterpret_cast<const v4i *>(ip + nn * LSTR + kb * 64 + kq * 16);
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][2], acc2, 0, 0, 0);
+        }
+        unsigned packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bs);
+            int q = min(max(ss >> 22, 0), 255);                              // Resample.c clip8
+            // keep the compiler from fusing two of these into v_ashr_pk_u8_i32: hipcc 7.2 assumes that
+            // instruction clears the upper half of its destination, gfx950 leaves the old bits there
+            asm volatile("" : "+v"(q));
+            packed |= (unsigned)q << (8 * i);
+        }
+        *reinterpret_cast<unsigned *>(op + nn * OSTR + gi * 16 + kq * 4) = packed;
+        if (gi == 3) {
+            lds_wave_sync();
+            const int n2 = tile * 16 + (lane >> 2), c16 = (lane & 3) * 16;
+            const v4i v = *reinterpret_cast<const v4i *>(op + (lane >> 2) * OSTR + c16);
+            const int line0 = q * 64 + c16;
+            if (n2 < nout) {
+                uint8_t *o = dst + (size_t)n2 * dpitch + line0;
+                if (pad_ok || line0 + 16 <= nlines) *reinterpret_cast<v4i_u1 *>(o) = v;
+                else
+                    for (int i = 0; line0 + i < nlines; i++) o[i] = (uint8_t)((unsigned)v[i >> 2] >> (8 * (i & 3)));
+            }
+        }
+    }
+    }
+}
+
+// B operand, kbase and bias of one pass.  cs: byte stride between the taps of one output (the
+// channel count for the horizontal pass over interleaved pixels, 1 for the vertical pass).
+static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32_t> &kk, int ksize, int nout_px, int cs,
+                     ThumbPlan::Mm &t) {
+    t = ThumbPlan::Mm();
+    t.nout = nout_px * cs;
+    t.ntiles = cdiv(t.nout, 16);
+    t.kbase.assign(t.ntiles, 0);
+    t.bias.assign((size_t)t.ntiles * 16, 0);
+    // first input byte of a tile, aligned down as far as that does not cost another 64-byte block
+    // (16-byte aligned line loads are cheaper for the memory pipeline, a third MFMA block is not)
+    int KB = 1;
+    for (int kalign = 16; kalign >= 1; kalign /= 4) {          // 16, 4, 1
+        KB = 1;
+        for (int T = 0; T < t.ntiles; T++) {
+            int lo = INT_MAX, hi = -1;
+            for (int j = 16 * T; j < std::min(16 * T + 16, t.nout); j++) {
+                const int xo = j / cs, ch = j % cs, xmin = bounds[2 * xo], xs = bounds[2 * xo + 1];
+                if (xs <= 0) continue;
+                lo = std::min(lo, xmin * cs + ch);
+                hi = std::max(hi, (xmin + xs - 1) * cs + ch);
+            }
+            if (hi < 0) { lo = 0; hi = 0; }
+            lo &= ~(kalign - 1);
+            t.kbase[T] = lo;
+            KB = std::max(KB, cdiv(hi - lo + 1, 64));
+        }
+        int KB1 = 1;                                            // blocks needed without any alignment
+        for (int T = 0; T < t.ntiles; T++) {
+            int lo = INT_MAX, hi = -1;
+            for (int j = 16 * T; j < std::min(16 * T + 16, t.nout); j++) {
+                const int xo = j / cs, ch = j % cs, xmin = bounds[2 * xo], xs = bounds[2 * xo + 1];
+                if (xs <= 0) continue;
+                lo = std::min(lo, xmin * cs + ch);
+                hi = std::max(hi, (xmin + xs - 1) * cs + ch);
+            }
+            if (hi >= 0) KB1 = std::max(KB1, cdiv(hi - lo + 1, 64));
+        }
+        if (KB == KB1) break;
+    }
+    if (KB > 2) return false;
+    t.KB = KB;
+    t.b.assign((size_t)t.ntiles * KB * 3 * 1024, 0);
+    for (int T = 0; T < t.ntiles; T++)
+        for (int nn = 0; nn < 16; nn++) {
+            const int j = 16 * T + nn;
+            if (j >= t.nout) continue;
+            const int xo = j / cs, ch = j % cs, xmin = bounds[2 * xo], xs = bounds[2 * xo + 1];
+            long long sum = 0;
+            for (int x = 0; x < xs; x++) {
+                const int coef = kk[(size_t)xo * ksize + x];
+                sum += coef;
+                const int k = (xmin + x) * cs + ch - t.kbase[T];
+                const int kb = k / 64, kq = (k % 64) / 16, bb = k % 16, lane = kq * 16 + nn;
+                const int d0 = ((coef + 128) & 255) - 128, c1 = (coef - d0) >> 8;
+                const int d1 = ((c1 + 128) & 255) - 128, d2 = (c1 - d1) >> 8;
+                if (d2 < -128 || d2 > 127) return false;
+                const int dg[3] = {d0, d1, d2};
+                for (int d = 0; d < 3; d++)
+                    t.b[(((size_t)(T * KB + kb) * 3 + d) * 64 + lane) * 16 + bb] = (unsigned char)(signed char)dg[d];
+            }
+            const long long bv = (1ll << 21) + 128 * sum;
+            if (bv > INT_MAX || bv < INT_MIN) return false;
+            t.bias[j] = (int32_t)bv;
+        }
+    return true;
+}
+
 // Plan of one thumbnail: host tables + scratch sizes.  Built once per (shape, request).
 int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
     p = ThumbPlan();
@@ -307,17 +499,48 @@ int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
         }
     }
     if (p.need_v) p.ksv = bicubic_coeffs(p.rh, 0.f, bh, p.oh, p.bv_, p.kv_);
+    p.mm_ok = p.need_h && p.need_v && !getenv("MRCHIP_THUMB_NO_MFMA") &&
+              build_mm(p.bh_, p.kh_, p.ksh, p.ow, c, p.mmh) && build_mm(p.bv_, p.kv_, p.ksv, p.oh, 1, p.mmv);
+    // one blob: [bh, kh, bv, kv, khT | per pass: kbase, bias, B operand (16-byte aligned)]
+    auto put = [&](const void *d, size_t bytes) {
+        size_t off = (p.blob_.size() + 15) & ~(size_t)15;
+        p.blob_.resize(off + bytes);
+        if (bytes) memcpy(p.blob_.data() + off, d, bytes);
+        return off;
+    };
+    p.off_bh = put(p.bh_.data(), p.bh_.size() * 4);
+    p.off_kh = put(p.kh_.data(), p.kh_.size() * 4);
+    p.off_bv = put(p.bv_.data(), p.bv_.size() * 4);
+    p.off_kv = put(p.kv_.data(), p.kv_.size() * 4);
+    p.off_khT = put(p.khT_.data(), p.khT_.size() * 4);
+    if (p.mm_ok) {
+        ThumbPlan::Mm *mm[2] = {&p.mmh, &p.mmv};
+        for (int i = 0; i < 2; i++) {
+            p.off_mm[i][0] = put(mm[i]->kbase.data(), mm[i]->kbase.size() * 4);
+            p.off_mm[i][1] = put(mm[i]->bias.data(), mm[i]->bias.size() * 4);
+            p.off_mm[i][2] = put(mm[i]->b.data(), mm[i]->b.size());
+        }
+    }
+    p.blob_.resize(p.blob_.size() + 64);
     return 0;
 }
 
-size_t ThumbPlan_table_bytes(const ThumbPlan &p) {
-    return (p.bh_.size() + p.kh_.size() + p.bv_.size() + p.kv_.size() + p.khT_.size()) * sizeof(int32_t) + 64;
+size_t ThumbPlan_table_bytes(const ThumbPlan &p) { return p.blob_.size(); }
+
+void ThumbPlan_scratch2_dims(const ThumbPlan &p, int *width_bytes, int *rows) {
+    if (p.mm_ok) {           // transposed: one line per output byte of the horizontal pass, K slack at the end
+        *width_bytes = round_up(p.rh, 64) + 128;
+        *rows = p.mmh.ntiles * 16;
+    } else {
+        *width_bytes = p.ow * p.c;
+        *rows = p.rh;
+    }
 }
 
 // d_tables: device copy of [bh_, kh_, bv_, kv_] in that order (int32), made by the caller.
 // scratch1: rw*rh*c per page (reduce output, if any); scratch2: ow*rh*c per page (horizontal pass output)
 int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
-                          const int32_t *d_tables, Plane scratch1, Plane scratch2, int npages) {
+                          const void *d_tables, Plane scratch1, Plane scratch2, int npages) {
     const int c = p.c;
     if (!p.changed) {
         for (int i = 0; i < npages; i++)
@@ -335,8 +558,35 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
                                   cur.stride, cw, ch_, c, p.fx, p.fy, scratch1.p, scratch1.pitch, scratch1.stride, p.rw, p.rh));
         cur = scratch1; cw = p.rw; ch_ = p.rh;
     }
-    const int32_t *d_bh = d_tables, *d_kh = d_bh + p.bh_.size(), *d_bv = d_kh + p.kh_.size(), *d_kv = d_bv + p.bv_.size();
-    const int32_t *d_khT = d_kv + p.kv_.size();
+    const char *tb = reinterpret_cast<const char *>(d_tables);
+    auto tptr = [&](size_t off) { return reinterpret_cast<const int32_t *>(tb + off); };
+    const int32_t *d_bh = tptr(p.off_bh), *d_kh = tptr(p.off_kh), *d_bv = tptr(p.off_bv), *d_kv = tptr(p.off_kv);
+    const int32_t *d_khT = tptr(p.off_khT);
+    if (p.mm_ok) {
+        // horizontal: lines = image rows -> scratch2 transposed [output byte][row]; vertical: lines = those -> dst
+        const int qpw = npages >= 16 ? 8 : 2;              // quads of 64 lines per wave
+        const ThumbPlan::Mm *mm[2] = {&p.mmh, &p.mmv};
+        for (int pass = 0; pass < 2; pass++) {
+            const ThumbPlan::Mm &M = *mm[pass];
+            const Plane in = pass == 0 ? cur : scratch2, out = pass == 0 ? scratch2 : dst;
+            const int nlines = pass == 0 ? ch_ : p.mmh.nout;
+            static const int wpb = getenv("MRCHIP_MM_WPB") ? atoi(getenv("MRCHIP_MM_WPB")) : 16;
+            const int gx = cdiv(M.ntiles, wpb), gy = cdiv(cdiv(nlines, 64), qpw);
+            const dim3 grid(round_up(gx * gy * npages, 8));
+            const double a = (pass == 0 && !red) ? alg : 0.0;
+            const char *nm = pass == 0 ? "thumb_resize_h" : "thumb_resize_v";
+            const v4i *bt = reinterpret_cast<const v4i *>(tb + p.off_mm[pass][2]);
+#define MM_LAUNCH(KBB, WW)                                                                                             \
+    LAUNCH(ctx, s, nm, a,                                                                                              \
+           hipLaunchKernelGGL((resize_mm_kernel<KBB, WW>), grid, dim3(64 * WW), 0, s, in.p, in.pitch, in.stride, nlines, \
+                              out.p, out.pitch, out.stride, M.nout, M.ntiles, tptr(p.off_mm[pass][0]),                  \
+                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages))
+            if (M.KB == 1) { if (wpb == 4) MM_LAUNCH(1, 4); else if (wpb == 8) MM_LAUNCH(1, 8); else MM_LAUNCH(1, 16); }
+            else { if (wpb == 4) MM_LAUNCH(2, 4); else if (wpb == 8) MM_LAUNCH(2, 8); else MM_LAUNCH(2, 16); }
+#undef MM_LAUNCH
+        }
+        return 0;
+    }
     if (p.need_h) {
         Plane o = p.need_v ? scratch2 : dst;
         const dim3 grid(cdiv(p.ow, 256), ch_, npages);

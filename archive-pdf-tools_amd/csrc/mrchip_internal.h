@@ -217,12 +217,24 @@ struct ThumbPlan {
     int rw = 0, rh = 0;       // size after reduce
     int need_h = 0, need_v = 0, ksh = 0, ksv = 0;
     std::vector<int32_t> bh_, kh_, bv_, kv_, khT_;   // khT_: kh_ transposed, padded to THUMB_MAXK taps
+    // Matrix-core path: a resize pass is the product of the pixel lines with a banded coefficient
+    // matrix.  Per tile of 16 outputs: first input byte (kbase), per output the constant term
+    // (bias), and the MFMA B operand (KB blocks of 64 input bytes x 3 balanced base-256 digits of
+    // the 22-bit coefficients, already in lane order).
+    struct Mm { int ntiles = 0, KB = 0, nout = 0; std::vector<int32_t> kbase, bias; std::vector<unsigned char> b; };
+    Mm mmh, mmv;
+    int mm_ok = 0;            // both passes present and each 16-output tile spans <= 128 input bytes
+    // every table in one blob (what the device copy holds), byte offsets of the parts
+    std::vector<unsigned char> blob_;
+    size_t off_bh = 0, off_kh = 0, off_bv = 0, off_kv = 0, off_khT = 0, off_mm[2][3] = {{0, 0, 0}, {0, 0, 0}};
 };
 int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h);
-size_t ThumbPlan_table_bytes(const ThumbPlan &p);
+size_t ThumbPlan_table_bytes(const ThumbPlan &p);          // == p.blob_.size(): copy p.blob_ to the device
+// per-page extent of the pass-to-pass scratch image (row-major ow*c x rh, or transposed + padded for the matrix-core path)
+void ThumbPlan_scratch2_dims(const ThumbPlan &p, int *width_bytes, int *rows);
 // dst: page i at dst + i*dstride (tight rows of dpitch bytes); scratch1/2 likewise with their strides
 int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
-                          const int32_t *d_tables, Plane scratch1, Plane scratch2, int npages);
+                          const void *d_tables, Plane scratch1, Plane scratch2, int npages);
 size_t sigma_scratch_bytes(int w, int h, int kind);
 // one noise estimate = one job (a page's central crop, or one bool threshold of an hOCR box)
 struct SigJob {

@@ -115,3 +115,29 @@ def test_gaussian_every_fused_radius_and_ragged_widths(radius):
         _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), r))
         exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
         assert np.array_equal(out, exp), (radius, h, w)
+
+
+@pytest.mark.parametrize('no_mfma', [False, True])
+def test_thumbnail_geometries_matrix_core_and_fallback(no_mfma, monkeypatch):
+    """The bicubic passes run on the MFMA units when both directions resize and a 16-output tile spans at most
+    128 input bytes (k_resample.hip resize_mm_kernel), otherwise -- or with MRCHIP_THUMB_NO_MFMA -- on the integer
+    VALU kernels.  Scale factors 1.3 .. 4 (+ Image.reduce beyond), gray and RGB, sizes that leave partial tiles
+    (outputs % 16), partial line quads (lines % 64) and odd row lengths."""
+    import ctypes as C
+    if no_mfma:
+        monkeypatch.setenv('MRCHIP_THUMB_NO_MFMA', '1')
+    lib, ctx = _lib.load(), _lib.default_context()
+    rng = np.random.RandomState(5)
+    cases = [((131, 257, 3), (100, 60)), ((700, 1000), (333, 233)), ((389, 515, 3), (129, 97)), ((70, 90, 3), (45, 35)),
+             ((1000, 64), (21, 333)), ((33, 2050, 3), (683, 11)), ((640, 480, 3), (369, 492)), ((1203, 901, 3), (112, 150)),
+             ((256, 256), (64, 64)), ((257, 255, 3), (85, 86))]
+    for shape, (rw, rh) in cases:
+        im = rng.randint(0, 256, shape).astype(np.uint8)
+        h, w = shape[:2]
+        c = 1 if im.ndim == 2 else 3
+        ow, oh = C.c_int(), C.c_int()
+        lib.mrchip_thumbnail_size(w, h, rw, rh, C.byref(ow), C.byref(oh))
+        out = np.empty((oh.value, ow.value) if c == 1 else (oh.value, ow.value, 3), np.uint8)
+        _lib.check(lib.mrchip_thumbnail(ctx.handle, _lib.ptr(np.ascontiguousarray(im)), w, h, c, rw, rh, _lib.ptr(out)))
+        exp = O.thumbnail(im, rw, rh)
+        assert out.shape == exp.shape and np.array_equal(out, exp), (shape, rw, rh, no_mfma)
