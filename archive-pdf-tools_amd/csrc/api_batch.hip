@@ -49,6 +49,7 @@ struct mrchip_batch {
     DevBuf gtmp;  int gtmp_pitch = 0;  size_t gtmp_stride = 0;     // float32 scratch of the blur
     DevBuf sig_scratch;  size_t sig_stride = 0;
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
+    DevBuf packed;  int packed_valid = 0;     // 1-bpp copy of the finished masks (made on first request)
     size_t dn_stride = 0, th_bytes = 0;
     ThumbPlan plan[2];
     int plan_req[2][2] = {{0, 0}, {0, 0}};
@@ -409,6 +410,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     if (denoise_fast)
         TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N));  // :388
     b->state = 4;
+    b->packed_valid = 0;
     return 0;
 }
 
@@ -417,6 +419,24 @@ MRCHIP_EXPORT int mrchip_batch_download_mask(mrchip_batch *b, int page, uint8_t 
     if (b->state < 4) { set_error("download_mask before mask_finish"); return MRCHIP_E_STATE; }
     if (page < 0 || page >= b->n || !mask) { set_error("download_mask: bad arguments"); return MRCHIP_E_ARG; }
     TRY(download_2d(b->s, mask, b->w, b->mask.pl.page(page), b->mask.pl.pitch, b->w, b->h));
+    HIP_TRY(hipStreamSynchronize(b->s));
+    return 0;
+}
+
+// The mask as the encoder wants it (mrc.py:474-520 makes a PIL mode '1' image of it): 1 bit per
+// pixel, MSB first, (w+7)/8 bytes per row -- an eighth of the bytes over PCIe.
+MRCHIP_EXPORT int mrchip_batch_download_mask_packed(mrchip_batch *b, int page, uint8_t *out) {
+    CHECK_B(b);
+    if (b->state < 4) { set_error("download_mask_packed before mask_finish"); return MRCHIP_E_STATE; }
+    if (page < 0 || page >= b->n || !out) { set_error("download_mask_packed: bad arguments"); return MRCHIP_E_ARG; }
+    const size_t per_page = ((size_t)((b->w + 7) / 8) * b->h + 255) & ~(size_t)255;
+    if (!b->packed_valid) {
+        if (!b->packed.p) TRY(b->packed.alloc(b->ctx, per_page * b->n + 256));
+        TRY(launch_pack_msb(b->ctx, b->s, b->mask.pl, b->w, b->h, b->packed.as<uint8_t>(), per_page, b->n));
+        b->packed_valid = 1;
+    }
+    HIP_TRY(hipMemcpyAsync(out, b->packed.as<uint8_t>() + per_page * page, (size_t)((b->w + 7) / 8) * b->h,
+                           hipMemcpyDeviceToHost, b->s));
     HIP_TRY(hipStreamSynchronize(b->s));
     return 0;
 }
@@ -577,6 +597,9 @@ MRCHIP_EXPORT int mrchip_page_mask_finish(mrchip_page *pg, const double *weights
 }
 MRCHIP_EXPORT int mrchip_page_download_mask(mrchip_page *pg, uint8_t *mask) {
     return mrchip_batch_download_mask(reinterpret_cast<mrchip_batch *>(pg), 0, mask);
+}
+MRCHIP_EXPORT int mrchip_page_download_mask_packed(mrchip_page *pg, uint8_t *out) {
+    return mrchip_batch_download_mask_packed(reinterpret_cast<mrchip_batch *>(pg), 0, out);
 }
 MRCHIP_EXPORT int mrchip_page_layer(mrchip_page *pg, int is_bg, double downsample, int *out_w, int *out_h, int *too_small) {
     mrchip_batch *b = reinterpret_cast<mrchip_batch *>(pg);

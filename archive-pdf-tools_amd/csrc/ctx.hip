@@ -225,3 +225,28 @@ MRCHIP_EXPORT int mrchip_prof_get(mrchip_ctx *ctx, int i, char *name, int name_l
     if (alg_bytes) *alg_bytes = e.alg_bytes;
     return 0;
 }
+
+MRCHIP_EXPORT int mrchip_hbm_copy_bandwidth(mrchip_ctx *ctx, size_t bytes, int reps, double *gbps) {
+    if (!ctx) { set_error("null context"); return MRCHIP_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!gbps || bytes < 4096 || reps < 1) { set_error("hbm_copy_bandwidth: bad arguments"); return MRCHIP_E_ARG; }
+    DevBuf a, b;
+    TRY(a.alloc(ctx, bytes));
+    TRY(b.alloc(ctx, bytes));
+    hipStream_t s = ctx->streams[0];
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipMemsetAsync(a.p, 1, bytes, s));
+    HIP_TRY(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, s));      // warm-up
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; i++) HIP_TRY(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbps = ms > 0 ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return 0;
+}

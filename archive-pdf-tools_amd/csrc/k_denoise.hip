@@ -55,6 +55,40 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int
     bits[(size_t)y * wpr + j] = word;
 }
 
+// 1 bit per pixel, most significant bit first, rows padded to whole bytes: the layout of a raw PBM
+// (P4) body and of PIL's mode '1' -- what mrc.encode_mrc_mask (mrc.py:474-520) turns the bool mask
+// into before it goes to jbig2/PNG.  One thread per output byte (8 mask bytes in).
+__device__ __forceinline__ unsigned nz_nibble_msb(unsigned m) {
+    unsigned t = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;
+    return (((t >> 7) * 0x08040201u) >> 24) & 0xFu;       // byte 0 -> bit 3 ... byte 3 -> bit 0
+}
+__global__ __launch_bounds__(256) void pack_msb_kernel(const uint8_t *mask, int pitch, size_t mstride, int w, int h,
+                                                       uint8_t *out, int bpr /* bytes per row */, size_t ostride) {
+    const int y = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= bpr) return;
+    mask += (size_t)blockIdx.z * mstride;
+    out += (size_t)blockIdx.z * ostride;
+    const uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 8;
+    unsigned v;
+    if (j * 8 + 8 <= w) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(row);
+        v = nz_nibble_msb(a.x) << 4 | nz_nibble_msb(a.y);
+    } else {
+        v = 0;
+        for (int i = 0; j * 8 + i < w; i++) v |= (row[i] ? 0x80u : 0u) >> i;
+    }
+    out[(size_t)y * bpr + j] = (uint8_t)v;
+}
+
+int launch_pack_msb(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, uint8_t *out, size_t ostride, int npages) {
+    const int bpr = (w + 7) / 8;
+    LAUNCH(ctx, s, "mask_pack_1bpp", 1.125 * w * h * npages,
+           hipLaunchKernelGGL(pack_msb_kernel, dim3(cdiv(bpr, 256), h, npages), dim3(256), 0, s, mask.p, mask.pitch, mask.stride,
+                              w, h, out, bpr, ostride));
+    return 0;
+}
+
 __device__ __forceinline__ unsigned spread_nibble(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
 __global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned *bits, int wpr, size_t bstride, uint8_t *mask,

@@ -258,6 +258,8 @@ int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, 
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
                          size_t bits_stride, int npages);
 size_t denoise_scratch_bytes(int w, int h);
+// 1 bpp MSB-first rows of (w+7)/8 bytes; page i at out + i*ostride
+int launch_pack_msb(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, uint8_t *out, size_t ostride, int npages);
 
 // host logic
 int thumbnail_size(int w, int h, int req_w, int req_h, int *ow, int *oh);

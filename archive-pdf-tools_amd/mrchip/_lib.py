@@ -50,6 +50,7 @@ SIGNATURES = {
     'mrchip_page_sigma': (C.c_int, [vp, f64p]),
     'mrchip_page_mask_finish': (C.c_int, [vp, f64p, C.c_int, C.c_int]),
     'mrchip_page_download_mask': (C.c_int, [vp, u8p]),
+    'mrchip_page_download_mask_packed': (C.c_int, [vp, u8p]),
     'mrchip_page_layer': (C.c_int, [vp, C.c_int, C.c_double, intp, intp, intp]),
     'mrchip_page_download_layer': (C.c_int, [vp, C.c_int, u8p]),
     'mrchip_page_sync': (C.c_int, [vp]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     'mrchip_batch_sigmas': (C.c_int, [vp, f64p]),
     'mrchip_batch_mask_finish': (C.c_int, [vp, f64p, intp, C.c_int]),
     'mrchip_batch_download_mask': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_download_mask_packed': (C.c_int, [vp, C.c_int, u8p]),
     'mrchip_batch_layers': (C.c_int, [vp, C.c_int, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
     'mrchip_batch_download_layer': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
     'mrchip_batch_sync': (C.c_int, [vp]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     'mrchip_prof_reset': (C.c_int, [vp]),
     'mrchip_prof_count': (C.c_int, [vp]),
     'mrchip_prof_get': (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), f64p, f64p]),
+    'mrchip_hbm_copy_bandwidth': (C.c_int, [vp, C.c_size_t, C.c_int, f64p]),
 }
 
 
@@ -139,6 +142,12 @@ class Context:
         hbm = C.c_size_t()
         check(load().mrchip_device_info(self.handle, name, 128, C.byref(cus), C.byref(hbm)))
         return {'name': name.value.decode(), 'cus': cus.value, 'hbm_bytes': hbm.value}
+
+    def hbm_copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """Measured device-to-device copy rate in GB/s (bytes read + written)."""
+        g = C.c_double()
+        check(load().mrchip_hbm_copy_bandwidth(self.handle, nbytes, reps, C.byref(g)))
+        return g.value
 
     def prof_enable(self, on=True):
         check(load().mrchip_prof_enable(self.handle, 1 if on else 0))

@@ -132,6 +132,10 @@ int mrchip_page_sigma(mrchip_page *pg, double *sigma_est);
 int mrchip_page_mask_finish(mrchip_page *pg, const double *weights, int radius, int denoise_fast);
 /* first yield: bool[h][w] */
 int mrchip_page_download_mask(mrchip_page *pg, uint8_t *mask);
+/* The same mask at 1 bit per pixel, most significant bit first, rows of (w+7)/8 bytes -- the raw
+ * PBM (P4) / PIL mode '1' layout mrc.encode_mrc_mask builds before jbig2/PNG (mrc.py:474-520;
+ * SURVEY.md 8f rank 1).  An eighth of the bytes cross PCIe. */
+int mrchip_page_download_mask_packed(mrchip_page *pg, uint8_t *packed);
 /* second / third yield (enqueue only): optimise (fg: n=3 on mask; bg: n=10 on
  * the inverted mask) + optional thumbnail.  downsample <= 0: none.
  * *too_small = 1 reproduces 'too-small-to-downsample' (mrc.py:429-431). */
@@ -161,6 +165,7 @@ int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est);
  * radius[npages]; both NULL = build the tables here with libm's exp */
 int mrchip_batch_mask_finish(mrchip_batch *b, const double *weights, const int *radius, int denoise_fast);
 int mrchip_batch_download_mask(mrchip_batch *b, int page, uint8_t *mask);
+int mrchip_batch_download_mask_packed(mrchip_batch *b, int page, uint8_t *packed);
 /* which: 1 = fg, 2 = bg, 3 = both (one launch).  downsample <= 0: none.
  * too_small: bit 0 fg, bit 1 bg ('too-small-to-downsample', mrc.py:429-431, 463-465) */
 int mrchip_batch_layers(mrchip_batch *b, int which, double fg_downsample, double bg_downsample,
@@ -182,6 +187,10 @@ int mrchip_prof_reset(mrchip_ctx *ctx);
 int mrchip_prof_count(mrchip_ctx *ctx);
 int mrchip_prof_get(mrchip_ctx *ctx, int i, char *name, int name_len, long long *launches,
                     double *total_ms, double *alg_bytes);
+/* Measured HBM ceiling to quote next to the 8 TB/s spec peak: device-to-device
+ * copy of `bytes` repeated `reps` times, timed with HIP events; *gbps = bytes read + written
+ * per second / 1e9. */
+int mrchip_hbm_copy_bandwidth(mrchip_ctx *ctx, size_t bytes, int reps, double *gbps);
 
 #ifdef __cplusplus
 }

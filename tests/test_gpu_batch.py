@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import mrc_oracle as O
-from mrchip import mrc, synth
+from mrchip import _lib, mrc, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -30,3 +30,35 @@ def test_batch_gray_and_repeatable():
         g = O.create_mrc_hocr_components(img, hocr, dpi=200, bg_downsample=4, denoise_mask='fast')
         em, ef, eb = next(g).copy(), next(g), next(g)
         assert np.array_equal(x[0], em) and np.array_equal(x[1], ef) and np.array_equal(x[2], eb)
+
+
+def test_packed_mask_matches_numpy_packbits_and_pil():
+    """the mask leaves the device at 1 bpp in the layout mrc.encode_mrc_mask builds
+    (PIL mode '1' == numpy.packbits rows, MSB first); widths that are not multiples of 8 / 32."""
+    ctx = _lib.default_context()
+    for (w, h, c) in [(403, 301, 3), (64, 40, 1), (1001, 77, 1), (7, 5, 3)]:
+        pages = []
+        for i in range(2):
+            img, hocr = synth.synth_page(w, h, c, seed=50 + i, noise_sigma=5.0, line_div=12)
+            pages.append((img, mrc.hocr_boxes(hocr, w, h)))
+        bt = mrc.Batch(ctx, 2, w, h, c)
+        for i, (img, boxes) in enumerate(pages):
+            bt.upload(i, img)
+            bt.set_boxes(i, boxes)
+        bt.mask_begin(51)
+        bt.mask_finish(bt.sigmas(), True)
+        for i in range(2):
+            mask = bt.download_mask(i)
+            packed = bt.download_mask_packed(i)
+            assert packed.shape == (h, (w + 7) // 8)
+            assert np.array_equal(packed, np.packbits(mask, axis=1))
+            pbm = mrc.packed_mask_to_pbm(packed, w, h)
+            assert pbm.startswith(b'P4\n%d %d\n' % (w, h)) and len(pbm) == len(b'P4\n%d %d\n' % (w, h)) + packed.size
+            try:
+                from PIL import Image
+            except ImportError:
+                continue
+            a = Image.frombytes('1', (w, h), packed.tobytes())
+            b = Image.fromarray(mask)
+            assert a.mode == b.mode == '1' and a.tobytes() == b.tobytes()
+        bt.close()
