@@ -24,6 +24,9 @@ __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
 
+typedef unsigned unsigned_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ unsigned ld_u32(const uint8_t *p) { return *reinterpret_cast<const unsigned_a1 *>(p); }
+
 template <class T>
 struct Db2 { T f[4]; };
 
@@ -61,52 +64,6 @@ struct SelState {
     double sigma;
 };
 
-template <class T>
-__global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> F, size_t dd_off) {
-    const SigJob J = jobs[blockIdx.z];
-    const int w = J.w, h = J.h, pitch = J.pitch, as_bool = J.as_bool;
-    const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
-    const int m = blockIdx.x * 256 + threadIdx.x;   // column of dd
-    const int k = blockIdx.y;                       // row of dd
-    if (blockIdx.x == 0 && blockIdx.y == 0) {       // reset this job's selection state
-        unsigned *z = reinterpret_cast<unsigned *>(J.scratch);
-        for (int i = threadIdx.x; i < (int)(sizeof(SelState) / 4); i += 256) z[i] = 0;
-    }
-    if (m >= w2 || k >= h2) return;
-    const uint8_t *src = J.src;
-    T *dd = reinterpret_cast<T *>(J.scratch + dd_off);
-    auto px = [&](int yy, int xx) -> T {
-        unsigned v = src[(size_t)yy * pitch + xx];
-        return as_bool ? (T)(v ? 1 : 0) : (T)v;
-    };
-    T v;
-    const int iy = 2 * k + 1, ix = 2 * m + 1;
-    if (iy >= 3 && iy < h && ix >= 3 && ix < w) {
-        // interior coefficient: all 16 taps in range, straight-line code in the same order as the
-        // generic path (axis 0 first: t[c] = ((0 + f0*x[iy]) + f1*x[iy-1]) + ..., then axis 1)
-        T t[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int xx = ix - c;
-            T sum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], px(iy - j, xx)));
-            t[c] = sum;
-        }
-        T sum = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], t[j]));
-        v = sum;
-    } else {
-        // border coefficient: PyWavelets' symmetric-extension order (axis 0 first, then axis 1)
-        auto tcol = [&](int xx) -> T {
-            return dwt_point<T>(F, h, iy, [&](int yy) { return px(yy, xx); });
-        };
-        v = dwt_point<T>(F, w, ix, tcol);
-    }
-    dd[(size_t)k * w2 + m] = v;
-}
-
 template <class T> struct Key;
 template <> struct Key<float> {
     using U = unsigned;
@@ -120,6 +77,106 @@ template <> struct Key<double> {
     __device__ static U of(double v) { return (U)__double_as_longlong(fabs(v)); }
     __device__ static double val(U k) { return __longlong_as_double((long long)k); }
 };
+
+// Selection state is cleared by its own tiny launch: the transform below already adds the first
+// digit's histogram into it.
+__global__ __launch_bounds__(256) void sel_reset_kernel(const SigJob *jobs) {
+    unsigned *z = reinterpret_cast<unsigned *>(jobs[blockIdx.x].scratch);
+    for (int i = threadIdx.x; i < (int)(sizeof(SelState) / 4); i += 256) z[i] = 0;
+}
+
+// dd coefficients + the histogram of their first (most significant) radix digit.
+// Lane = 4 adjacent coefficients of a row: their 4 x 10 input bytes come in as 3 (unaligned)
+// dwords per row, the axis-0 sums of the 10 columns are shared by neighbouring outputs, and the
+// four results leave together.  Same operation order per coefficient as the one-output form
+// (axis 0: ((0 + f0*x[i]) + f1*x[i-1]) + ..., then axis 1 likewise); coefficients whose taps leave
+// the array take PyWavelets' symmetric-extension order in dwt_point.  DWT_RPB rows per workgroup
+// share one LDS histogram.
+constexpr int DWT_RPB = 4;
+template <class T>
+__global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> F, size_t dd_off) {
+    using U = typename Key<T>::U;
+    const SigJob J = jobs[blockIdx.z];
+    const int w = J.w, h = J.h, pitch = J.pitch;
+    constexpr bool AS_BOOL = sizeof(T) == 8;               // the float64 path is PyWavelets' treatment of bool arrays
+    const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
+    __shared__ unsigned lh[NBIN];
+    for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int m0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // first of the lane's 4 columns of dd
+    const uint8_t *src = J.src;
+    T *dd = reinterpret_cast<T *>(J.scratch + dd_off);
+    auto cv = [&](unsigned v) -> T { return AS_BOOL ? (T)(v ? 1 : 0) : (T)v; };
+    auto px = [&](int yy, int xx) -> T { return cv(src[(size_t)yy * pitch + xx]); };
+    // The symmetric extension on the left / top is an index reflection with the taps still in
+    // ascending filter order, and so is the right / bottom one as long as at most two taps overhang
+    // (the two swapped products commute); three overhang only for the last coefficient of an odd
+    // length, which keeps PyWavelets' order in dwt_point.  Tiny arrays go there entirely.
+    const bool roomy = w >= 8 && h >= 4;
+    for (int rr = 0; rr < DWT_RPB; rr++) {
+        const int k = blockIdx.y * DWT_RPB + rr;            // row of dd
+        if (k >= h2 || m0 >= w2) break;
+        const int iy = 2 * k + 1;
+        const bool row_fast = roomy && iy <= h + 1;         // iy - j in [-2, h+1]: plain reflection
+        T out[4];
+        bool done[4] = {false, false, false, false};
+        if (row_fast && 2 * m0 + 1 <= w + 1) {
+            // bytes 2*m0-4 .. 2*m0+7 of rows iy-3 .. iy (reflected into the array); columns
+            // 2*m0-2 .. 2*m0+7 are taps.  Bytes outside the row are loaded but not used.
+            unsigned rw[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int yy = iy - j;
+                yy = yy < 0 ? -1 - yy : (yy >= h ? 2 * h - 1 - yy : yy);
+                const uint8_t *p = src + (size_t)yy * pitch + 2 * m0 - 4;
+#pragma unroll
+                for (int q = 0; q < 3; q++) rw[j][q] = ld_u32(p + 4 * q);
+            }
+            T t[12];
+#pragma unroll
+            for (int bi = 2; bi < 12; bi++) {
+                T sum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], cv((rw[j][bi >> 2] >> (8 * (bi & 3))) & 0xffu)));
+                t[bi] = sum;
+            }
+            if (m0 == 0) { t[2] = t[5]; t[3] = t[4]; }     // columns -2, -1 mirror columns 1, 0
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ix = 2 * (m0 + q) + 1;
+                if (ix <= w + 1) {                          // taps ix-3 .. ix; columns w, w+1 mirror w-1, w-2
+                    const T tv[4] = {ix == w + 1 ? t[2 * q + 2] : (ix == w ? t[2 * q + 4] : t[2 * q + 5]),
+                                     ix == w + 1 ? t[2 * q + 3] : t[2 * q + 4], t[2 * q + 3], t[2 * q + 2]};
+                    T sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sum = add_rn(sum, mul_rn(F.f[j], tv[j]));
+                    out[q] = sum;
+                    done[q] = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!done[q] && m0 + q < w2) {
+                const int ix = 2 * (m0 + q) + 1;
+                auto tcol = [&](int xx) -> T { return dwt_point<T>(F, h, iy, [&](int yy) { return px(yy, xx); }); };
+                out[q] = dwt_point<T>(F, w, ix, tcol);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (m0 + q < w2) {
+                dd[(size_t)k * w2 + m0 + q] = out[q];
+                if (out[q] != (T)0) atomicAdd(&lh[(unsigned)(Key<T>::of(out[q]) >> (Key<T>::BITS - DIG))], 1u);
+            }
+    }
+    __syncthreads();
+    SelState *st = reinterpret_cast<SelState *>(J.scratch);
+    for (int i = threadIdx.x; i < NBIN; i += 256) {
+        const unsigned c = lh[i];
+        if (c) { atomicAdd(&st->hist[0][i], c); atomicAdd(&st->hist[1][i], c); }
+    }
+}
 
 // histogram of the digit at `shift` (width `bits`) among the non-zero |dd| whose higher
 // bits equal prefix[r]
@@ -240,9 +297,10 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const
         maxn = std::max(maxn, (size_t)w2 * h2);
         alg += (double)h_jobs[i].w * h_jobs[i].h;
     }
+    LAUNCH(ctx, s, "median_reset", 0.0, hipLaunchKernelGGL(sel_reset_kernel, dim3(njobs), dim3(256), 0, s, d_jobs));
     LAUNCH(ctx, s, sizeof(T) == 4 ? "dwt_dd_f32" : "dwt_dd_f64", alg,
-           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(maxw2, 256), maxh2, njobs), dim3(256), 0, s, d_jobs, F,
-                              dd_offset()));
+           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(maxw2, 1024), cdiv(maxh2, DWT_RPB), njobs), dim3(256), 0, s,
+                              d_jobs, F, dd_offset()));
     const int blocks = (int)std::min<size_t>(njobs > 8 ? 64 : 512, (maxn + 255) / 256);
     int shift = Key<T>::BITS;
     int first = 1;
@@ -250,9 +308,10 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const
         const int bits = shift >= DIG ? DIG : shift;
         shift -= bits;
         const int last = shift == 0;
-        LAUNCH(ctx, s, "median_hist", 0.0,
-               hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks, njobs), dim3(256), 0, s, d_jobs, dd_offset(), shift,
-                                  bits, first));
+        if (!first)      // the first digit's histogram came with the transform
+            LAUNCH(ctx, s, "median_hist", 0.0,
+                   hipLaunchKernelGGL((sel_hist_kernel<T>), dim3(blocks, njobs), dim3(256), 0, s, d_jobs, dd_offset(), shift,
+                                      bits, first));
         LAUNCH(ctx, s, "median_scan", 0.0,
                hipLaunchKernelGGL((sel_scan_kernel<T>), dim3(njobs), dim3(64), 0, s, d_jobs, bits, first, last, d_sigma));
         first = 0;
