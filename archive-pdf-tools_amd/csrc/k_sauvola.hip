@@ -34,6 +34,7 @@ struct SauvolaParams {
     int th;           // output rows per tile
 };
 
+
 // inclusive wave scan (64 lanes) with DPP row shifts + row broadcasts (GFX9)
 __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
     unsigned x = v;
@@ -94,13 +95,19 @@ __device__ __forceinline__ bool sauvola_form(unsigned mean_i, unsigned qd_i, uns
     return kpos ? (neg || (lhs <= rhs)) : (neg && (lhs >= rhs));
 }
 
+// floor(S / c) without a correction step when S < 2^20: floor((S + 0.5) / c) == floor(S / c) for
+// integers, (S + 0.5)/c is at least 0.5/c away from an integer, and the fp32 evaluation (S exact,
+// rc and the fma one rounding each) is off by less than q * 2^-22 < 0.5/c  <=>  S < 2^21.
+__device__ __forceinline__ unsigned mean_small(unsigned S, float rc, float hrc) {
+    return (unsigned)__builtin_fmaf((float)S, rc, hrc);
+}
+
 // Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
 // (wh-1)-row warm-up).  (An LDS ring of the last wh rows was tried: it removes the re-reads but
 // caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
-template <int K, bool MULTI>
+template <int K, bool MULTI, bool SMALL>
 __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
-    constexpr int CW = 64 * K;
     constexpr int KD = K / 4;
     constexpr int PF = 4;                              // rows in flight
     // Prefix rows in LDS, transposed: strip column ci = K*t + i lives at [i][t + PL].  A wave's
@@ -142,7 +149,6 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         }
         vmask[q] = m;
     }
-    const uint8_t *src0 = job.src + c0;
     // all outputs of this strip see the full window width -> count is wave-uniform per row
     const bool full_cols = (X0 - l + 1 >= 0) && (X0 + nout - 1 + r <= w - 1);
 
@@ -166,9 +172,14 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
     // row is USED several iterations later (masking at load time would put an s_waitcnt right here).
     // Rows outside the image are skipped where they are used (wave-uniform tests).
     typedef const unsigned __attribute__((address_space(1))) *gc_u32p;
+    // wave-uniform row base (scalar registers) + the lane's 32-bit byte offset: the load takes the
+    // SGPR-base addressing mode and costs no 64-bit vector address arithmetic
+    const uint8_t *srcA = job.src + Xa;
+    const unsigned loff = (unsigned)(K * lane);
     auto gload = [&](int yy, unsigned (&wv)[KD]) {
         const int yc = min(max(yy, 0), h - 1);
-        gc_u32p p = (gc_u32p)(src0 + (size_t)yc * job.src_pitch);
+        const uint8_t *rowp = srcA + (size_t)yc * job.src_pitch;          // uniform
+        gc_u32p p = (gc_u32p)(rowp + loff);
 #pragma unroll
         for (int q = 0; q < KD; q++) wv[q] = p[q];
     };
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
     auto mload = [&](int yy, unsigned (&wv)[KD]) {
         if (do_or && dst_al) {
             const int yc = min(max(yy, 0), h - 1);
-            gc_u32q p = (gc_u32q)(job.dst + (size_t)yc * job.dst_pitch + c0);
+            const uint8_t *rowd = job.dst + Xa + (size_t)yc * job.dst_pitch;  // uniform
+            gc_u32q p = (gc_u32q)(rowd + loff);
 #pragma unroll
             for (int q = 0; q < KD; q++) wv[q] = p[q];
         } else {
@@ -276,7 +288,8 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 rc = __builtin_amdgcn_rcpf((float)count);
             }
             const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
-            const unsigned mean_i = div_exact(S, count, rc);            // pyx:144 (cdivision)
+            const float hrc = 0.5f * rc;
+            const unsigned mean_i = SMALL ? mean_small(S, rc, hrc) : div_exact(S, count, rc);   // pyx:144 (cdivision)
             const unsigned qd_i = div_exact(Q, count, rc);              // pyx:145
             const bool form = sauvola_form(mean_i, qd_i, px, kpos, P.km1, P.k2);
             const unsigned bit = valid ? ((form ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;   // pyx:153 (+ mrc.py:85)
@@ -286,7 +299,8 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 // the same window on the image 255-p (mrc.py:224, 235)
                 const unsigned Si = __umul24(255u, count) - S;
                 const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
-                const bool fi = sauvola_form(div_exact(Si, count, rc), div_exact(Qi, count, rc), 255u - px, kpos, P.km1, P.k2);
+                const unsigned mi = SMALL ? mean_small(Si, rc, hrc) : div_exact(Si, count, rc);
+                const bool fi = sauvola_form(mi, div_exact(Qi, count, rc), 255u - px, kpos, P.km1, P.k2);
                 const unsigned bi = valid ? ((fi ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;
                 outb[i / 4] |= bi << (8 * (i & 3));
                 ones_b += bi;
@@ -352,13 +366,15 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     if (const char *e = getenv("MRCHIP_SAUVOLA_TH")) { int v = atoi(e); if (v >= 8) th = v; }   // tuning knob
     P.th = th;
     dim3 grid(strips, cdiv(maxh, th), njobs);
-    if (njobs == 1 && !d_jobs) {
-        LAUNCH(ctx, s, "sauvola", alg_bytes,
-               hipLaunchKernelGGL((sauvola_kernel<K, false>), grid, dim3(64), 0, s, h_jobs[0], nullptr, P));
-    } else {
-        LAUNCH(ctx, s, h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola", alg_bytes,
-               hipLaunchKernelGGL((sauvola_kernel<K, true>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
-    }
+    // window sums below 2^20: the mean's division needs no correction step (mean_small)
+    const bool small_s = 255ll * P.ww * P.wh < (1ll << 20);
+    const char *nm = (njobs == 1 && !d_jobs) ? "sauvola" : (h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola");
+#define SV_LAUNCH(MULTI, SMALL)                                                                                   \
+    LAUNCH(ctx, s, nm, alg_bytes,                                                                                 \
+           hipLaunchKernelGGL((sauvola_kernel<K, MULTI, SMALL>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P))
+    if (njobs == 1 && !d_jobs) { if (small_s) SV_LAUNCH(false, true); else SV_LAUNCH(false, false); }
+    else { if (small_s) SV_LAUNCH(true, true); else SV_LAUNCH(true, false); }
+#undef SV_LAUNCH
     return 0;
 }
 
