@@ -177,13 +177,18 @@ MRCHIP_EXPORT int mrchip_thumbnail_size(int w, int h, int req_w, int req_h, int 
 
 MRCHIP_EXPORT int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels, int req_w, int req_h,
                                    uint8_t *out) {
+    return mrchip_thumbnail_ex(ctx, in, w, h, channels, req_w, req_h, MRCHIP_FILTER_BICUBIC, 2.0, out);
+}
+
+MRCHIP_EXPORT int mrchip_thumbnail_ex(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels, int req_w, int req_h,
+                                      int filter, double reducing_gap, uint8_t *out) {
     CHECK_CTX(ctx);
     if (!in || !out || w <= 0 || h <= 0 || req_w <= 0 || req_h <= 0 || (channels != 1 && channels != 3)) {
         set_error("thumbnail: bad arguments");
         return MRCHIP_E_ARG;
     }
     ThumbPlan p;
-    TRY(ThumbPlan_build(p, w, h, channels, req_w, req_h));
+    TRY(ThumbPlan_build(p, w, h, channels, req_w, req_h, filter, reducing_gap));
     if (!p.changed) { memcpy(out, in, (size_t)w * h * channels); return 0; }
     hipStream_t s = ctx->streams[0];
     Img8 src;

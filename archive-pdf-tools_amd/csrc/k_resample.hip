@@ -44,12 +44,20 @@ static double bicubic_filter(double x) {
     return 0.0;
 }
 
-// Resample.c precompute_coeffs + normalize_coeffs_8bpc; box edges are float32 like Pillow's
-int bicubic_coeffs(int in_size, float in0, float in1, int out_size, std::vector<int32_t> &bounds,
-                   std::vector<int32_t> &kk) {
+// Resample.c sinc_filter / lanczos_filter (support 3): the page-ingest downsample, recode.py:368-372
+static double lanczos_filter(double x) {
+    auto sinc = [](double v) { if (v == 0.0) return 1.0; v = v * 3.14159265358979323846; return sin(v) / v; };
+    if (-3.0 <= x && x < 3.0) return sinc(x) * sinc(x / 3);
+    return 0.0;
+}
+
+// Resample.c precompute_coeffs + normalize_coeffs_8bpc; box edges are float32 like Pillow's.
+// filter: MRCHIP_FILTER_BICUBIC (support 2) or MRCHIP_FILTER_LANCZOS (support 3)
+int resample_coeffs(int filter, int in_size, float in0, float in1, int out_size, std::vector<int32_t> &bounds,
+                    std::vector<int32_t> &kk) {
     double scale = (double)(in1 - in0) / out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    double support = 2.0 * filterscale;
+    double support = (filter == MRCHIP_FILTER_LANCZOS ? 3.0 : 2.0) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     bounds.assign((size_t)out_size * 2, 0);
     kk.assign((size_t)out_size * ksize, 0);
@@ -64,7 +72,8 @@ int bicubic_coeffs(int in_size, float in0, float in1, int out_size, std::vector<
         xmax -= xmin;
         int x;
         for (x = 0; x < xmax; x++) {
-            double wv = bicubic_filter((x + xmin - center + 0.5) * ss);
+            double wv = filter == MRCHIP_FILTER_LANCZOS ? lanczos_filter((x + xmin - center + 0.5) * ss)
+                                                        : bicubic_filter((x + xmin - center + 0.5) * ss);
             k[x] = wv; ww += wv;
         }
         for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
@@ -474,14 +483,22 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
 }
 
 // Plan of one thumbnail: host tables + scratch sizes.  Built once per (shape, request).
-int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
+int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h, int filter, double reducing_gap) {
     p = ThumbPlan();
     p.w = w; p.h = h; p.c = c;
+    p.filter = filter; p.reducing_gap = reducing_gap;
+    if (filter != MRCHIP_FILTER_BICUBIC && filter != MRCHIP_FILTER_LANCZOS) {
+        set_error("thumbnail: unknown filter %d", filter);
+        return MRCHIP_E_ARG;
+    }
     p.changed = thumbnail_size(w, h, req_w, req_h, &p.ow, &p.oh);
     if (!p.changed) return 0;
-    // Image.resize: factor = int(extent / size / reducing_gap) or 1   (reducing_gap = 2.0)
-    p.fx = (int)((double)w / p.ow / 2.0); if (p.fx < 1) p.fx = 1;
-    p.fy = (int)((double)h / p.oh / 2.0); if (p.fy < 1) p.fy = 1;
+    // Image.resize: factor = int(extent / size / reducing_gap) or 1; reducing_gap None (<= 0 here): no reduce
+    p.fx = p.fy = 1;
+    if (reducing_gap > 0) {
+        p.fx = (int)((double)w / p.ow / reducing_gap); if (p.fx < 1) p.fx = 1;
+        p.fy = (int)((double)h / p.oh / reducing_gap); if (p.fy < 1) p.fy = 1;
+    }
     float bw = (float)w, bh = (float)h;
     p.rw = w; p.rh = h;
     if (p.fx > 1 || p.fy > 1) {
@@ -491,14 +508,14 @@ int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h) {
     p.need_h = (p.ow != p.rw) || (bw != (float)p.ow);
     p.need_v = (p.oh != p.rh) || (bh != (float)p.oh);
     if (p.need_h) {
-        p.ksh = bicubic_coeffs(p.rw, 0.f, bw, p.ow, p.bh_, p.kh_);
+        p.ksh = resample_coeffs(filter, p.rw, 0.f, bw, p.ow, p.bh_, p.kh_);
         if (p.ksh <= THUMB_MAXK) {                 // transposed, zero-padded to THUMB_MAXK taps
             p.khT_.assign((size_t)THUMB_MAXK * p.ow, 0);
             for (int xx = 0; xx < p.ow; xx++)
                 for (int x = 0; x < p.ksh; x++) p.khT_[(size_t)x * p.ow + xx] = p.kh_[(size_t)xx * p.ksh + x];
         }
     }
-    if (p.need_v) p.ksv = bicubic_coeffs(p.rh, 0.f, bh, p.oh, p.bv_, p.kv_);
+    if (p.need_v) p.ksv = resample_coeffs(filter, p.rh, 0.f, bh, p.oh, p.bv_, p.kv_);
     p.mm_ok = p.need_h && p.need_v && !getenv("MRCHIP_THUMB_NO_MFMA") &&
               build_mm(p.bh_, p.kh_, p.ksh, p.ow, c, p.mmh) && build_mm(p.bv_, p.kv_, p.ksv, p.oh, 1, p.mmv);
     // one blob: [bh, kh, bv, kv, khT | per pass: kbase, bias, B operand (16-byte aligned)]

@@ -211,6 +211,7 @@ constexpr int THUMB_MAXK = 20;
 // thumbnail plan: host-side size rule + fixed-point coefficient tables
 struct ThumbPlan {
     int w = 0, h = 0, c = 1;
+    int filter = 0;  double reducing_gap = 2.0;     // Image.thumbnail's resample / reducing_gap
     int changed = 0;          // 0: image left untouched
     int ow = 0, oh = 0;       // output size
     int fx = 1, fy = 1;       // Image.reduce factors
@@ -228,7 +229,8 @@ struct ThumbPlan {
     std::vector<unsigned char> blob_;
     size_t off_bh = 0, off_kh = 0, off_bv = 0, off_kv = 0, off_khT = 0, off_mm[2][3] = {{0, 0, 0}, {0, 0, 0}};
 };
-int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h);
+int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h, int filter = 0 /* MRCHIP_FILTER_BICUBIC */,
+                    double reducing_gap = 2.0);
 size_t ThumbPlan_table_bytes(const ThumbPlan &p);          // == p.blob_.size(): copy p.blob_ to the device
 // per-page extent of the pass-to-pass scratch image (row-major ow*c x rh, or transposed + padded for the matrix-core path)
 void ThumbPlan_scratch2_dims(const ThumbPlan &p, int *width_bytes, int *rows);

@@ -41,6 +41,7 @@ SIGNATURES = {
     'mrchip_gaussian_u8': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, f64p, C.c_int]),
     'mrchip_thumbnail_size': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, intp, intp]),
     'mrchip_thumbnail': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p]),
+    'mrchip_thumbnail_ex': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, u8p]),
     'mrchip_window_for_dpi': (C.c_int, [C.c_int, C.c_double]),
     'mrchip_hocr_mask': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p]),
     'mrchip_page_create': (vp, [vp, C.c_int, C.c_int, C.c_int]),

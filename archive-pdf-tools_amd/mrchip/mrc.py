@@ -415,3 +415,32 @@ def packed_mask_to_pbm(packed, w, h):
     if packed.shape != (h, (w + 7) // 8):
         raise ValueError('packed mask shape %r does not match %dx%d' % (packed.shape, w, h))
     return b'P4\n%d %d\n' % (w, h) + packed.tobytes()
+
+
+_FILTERS = {'bicubic': 0, 'lanczos': 1}
+
+
+def thumbnail(arr, size, resample='bicubic', reducing_gap=2.0, ctx=None):
+    """`im = Image.fromarray(arr); im.thumbnail(size, resample=..., reducing_gap=...); np.array(im)` on the
+    device.  `size` may hold floats like PIL's (floored).  The layer downsample of mrc.py:422-428 is the
+    default (BICUBIC, 2.0); the page-ingest downsample of recode.py:368-372 is
+    `thumbnail(arr, (w / downsample, h / downsample), resample='lanczos', reducing_gap=None)`."""
+    import math
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError('thumbnail: uint8[H,W] or uint8[H,W,3] expected')
+    if resample not in _FILTERS:
+        raise ValueError('thumbnail: resample must be one of %s' % sorted(_FILTERS))
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else 3
+    rw, rh = math.floor(size[0]), math.floor(size[1])
+    if rw <= 0 or rh <= 0:
+        raise ValueError('thumbnail: requested size must be positive')
+    lib = _lib.load()
+    ctx = ctx or _lib.default_context()
+    ow, oh = C.c_int(), C.c_int()
+    lib.mrchip_thumbnail_size(w, h, rw, rh, C.byref(ow), C.byref(oh))
+    out = np.empty((oh.value, ow.value) if c == 1 else (oh.value, ow.value, 3), np.uint8)
+    _lib.check(lib.mrchip_thumbnail_ex(ctx.handle, _lib.ptr(a), w, h, c, rw, rh, _FILTERS[resample],
+                                       float(reducing_gap) if reducing_gap else 0.0, _lib.ptr(out)), 'mrchip_thumbnail_ex')
+    return out

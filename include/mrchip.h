@@ -104,6 +104,12 @@ int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *out, int w
 int mrchip_thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h);
 int mrchip_thumbnail(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels,
                      int req_w, int req_h, uint8_t *out /* out_w*out_h*channels */);
+/* PIL Image.thumbnail((req_w, req_h), resample=filter, reducing_gap=gap) -- the page-ingest
+ * downsample of recode.py:368-372 is (LANCZOS, None); reducing_gap <= 0 stands for None (no
+ * Image.reduce step).  Same size rule as above (req_* = floor of the float size PIL is given). */
+enum { MRCHIP_FILTER_BICUBIC = 0, MRCHIP_FILTER_LANCZOS = 1 };
+int mrchip_thumbnail_ex(mrchip_ctx *ctx, const uint8_t *in, int w, int h, int channels,
+                        int req_w, int req_h, int filter, double reducing_gap, uint8_t *out);
 
 /* ---- internetarchivepdf/mrc.py ------------------------------------------- */
 /* mrc.threshold_image window rule -- mrc.py:68-75. */

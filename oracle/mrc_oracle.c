@@ -581,24 +581,45 @@ static double bicubic_filter(double x)
     return 0.0;
 }
 
+/* Resample.c sinc_filter / lanczos_filter (support 3.0): the filter of the page-ingest downsample,
+ * recode.py:368-372 (Image.thumbnail(..., resample=Image.LANCZOS, reducing_gap=None)). */
+static double sinc_filter(double x)
+{
+    if (x == 0.0) return 1.0;
+    x = x * 3.14159265358979323846;     /* M_PI */
+    return sin(x) / x;
+}
+static double lanczos_filter(double x)
+{
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+/* filter ids shared with include/mrchip.h: 0 = BICUBIC (support 2), 1 = LANCZOS (support 3) */
+static double filter_support(int filter) { return filter == 1 ? 3.0 : 2.0; }
+static double filter_eval(int filter, double x) { return filter == 1 ? lanczos_filter(x) : bicubic_filter(x); }
+
 /* Resample.c precompute_coeffs + normalize_coeffs_8bpc.  in0/in1 are float32
  * (the box is passed to C as float). Returns ksize; bounds[2*xx]=xmin,
  * bounds[2*xx+1]=count; kk[xx*ksize + i] fixed-point weights. */
-ORC_API int orc_bicubic_ksize(int in_size, float in0, float in1, int out_size)
+ORC_API int orc_resample_ksize(int filter, int in_size, float in0, float in1, int out_size)
 {
     (void)in_size;
     double scale = (double)(in1 - in0) / out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    double support = 2.0 * filterscale;
+    double support = filter_support(filter) * filterscale;
     return (int)ceil(support) * 2 + 1;
 }
+ORC_API int orc_bicubic_ksize(int in_size, float in0, float in1, int out_size)
+{
+    return orc_resample_ksize(0, in_size, in0, in1, out_size);
+}
 
-ORC_API int orc_bicubic_coeffs(int in_size, float in0, float in1, int out_size,
-                               int32_t *bounds, int32_t *kk)
+ORC_API int orc_resample_coeffs(int filter, int in_size, float in0, float in1, int out_size,
+                                int32_t *bounds, int32_t *kk)
 {
     double scale = (double)(in1 - in0) / out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    double support = 2.0 * filterscale;
+    double support = filter_support(filter) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     double *k = (double *)malloc((size_t)ksize * sizeof(double));
     if (!k) return -1;
@@ -612,7 +633,7 @@ ORC_API int orc_bicubic_coeffs(int in_size, float in0, float in1, int out_size,
         xmax -= xmin;
         int x;
         for (x = 0; x < xmax; x++) {
-            double wv = bicubic_filter((x + xmin - center + 0.5) * ss);
+            double wv = filter_eval(filter, (x + xmin - center + 0.5) * ss);
             k[x] = wv; ww += wv;
         }
         for (x = 0; x < xmax; x++) if (ww != 0.0) k[x] /= ww;
@@ -627,15 +648,20 @@ ORC_API int orc_bicubic_coeffs(int in_size, float in0, float in1, int out_size,
     return ksize;
 }
 
+ORC_API int orc_bicubic_coeffs(int in_size, float in0, float in1, int out_size, int32_t *bounds, int32_t *kk)
+{
+    return orc_resample_coeffs(0, in_size, in0, in1, out_size, bounds, kk);
+}
+
 static inline uint8_t clip8(int32_t v)
 {
     v >>= 22;                       /* arithmetic shift, as Pillow's clip8 lookup */
     return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v);
 }
 
-/* Image.resize(size, BICUBIC, box=(0,0,bw,bh)) on 8-bit images. */
-ORC_API int orc_resize_bicubic(const uint8_t *in, int w, int h, int c,
-                               float box_w, float box_h, int ow, int oh, uint8_t *out)
+/* Image.resize(size, filter, box=(0,0,bw,bh)) on 8-bit images. */
+ORC_API int orc_resize(int filter, const uint8_t *in, int w, int h, int c,
+                       float box_w, float box_h, int ow, int oh, uint8_t *out)
 {
     int need_h = (ow != w) || (box_w != (float)ow);
     int need_v = (oh != h) || (box_h != (float)oh);
@@ -643,12 +669,12 @@ ORC_API int orc_resize_bicubic(const uint8_t *in, int w, int h, int c,
     uint8_t *tmp = NULL;
     int cur_w = w;
     if (need_h) {
-        int ks = orc_bicubic_ksize(w, 0.f, box_w, ow);
+        int ks = orc_resample_ksize(filter, w, 0.f, box_w, ow);
         int32_t *b = (int32_t *)malloc((size_t)ow * 2 * sizeof(int32_t));
         int32_t *kk = (int32_t *)malloc((size_t)ow * ks * sizeof(int32_t));
         tmp = (uint8_t *)malloc((size_t)ow * h * c);
         if (!b || !kk || !tmp) { free(b); free(kk); free(tmp); return -1; }
-        orc_bicubic_coeffs(w, 0.f, box_w, ow, b, kk);
+        orc_resample_coeffs(filter, w, 0.f, box_w, ow, b, kk);
         for (int y = 0; y < h; y++)
             for (int xx = 0; xx < ow; xx++) {
                 int xmin = b[2 * xx], n = b[2 * xx + 1];
@@ -663,11 +689,11 @@ ORC_API int orc_resize_bicubic(const uint8_t *in, int w, int h, int c,
         src = tmp; cur_w = ow;
     }
     if (need_v) {
-        int ks = orc_bicubic_ksize(h, 0.f, box_h, oh);
+        int ks = orc_resample_ksize(filter, h, 0.f, box_h, oh);
         int32_t *b = (int32_t *)malloc((size_t)oh * 2 * sizeof(int32_t));
         int32_t *kk = (int32_t *)malloc((size_t)oh * ks * sizeof(int32_t));
         if (!b || !kk) { free(b); free(kk); free(tmp); return -1; }
-        orc_bicubic_coeffs(h, 0.f, box_h, oh, b, kk);
+        orc_resample_coeffs(filter, h, 0.f, box_h, oh, b, kk);
         for (int yy = 0; yy < oh; yy++) {
             int ymin = b[2 * yy], n = b[2 * yy + 1];
             const int32_t *ky = kk + (size_t)yy * ks;
@@ -685,9 +711,16 @@ ORC_API int orc_resize_bicubic(const uint8_t *in, int w, int h, int c,
     return 0;
 }
 
-/* Image.thumbnail((req_w, req_h)) with the defaults BICUBIC / reducing_gap=2.0.
- * out must hold ow*oh*c bytes with (ow,oh) from orc_thumbnail_size. */
-ORC_API int orc_thumbnail(const uint8_t *in, int w, int h, int c, int req_w, int req_h, uint8_t *out)
+ORC_API int orc_resize_bicubic(const uint8_t *in, int w, int h, int c,
+                               float box_w, float box_h, int ow, int oh, uint8_t *out)
+{
+    return orc_resize(0, in, w, h, c, box_w, box_h, ow, oh, out);
+}
+
+/* Image.thumbnail((req_w, req_h), resample=filter, reducing_gap=gap); gap <= 0 means None (no
+ * Image.reduce step).  out must hold ow*oh*c bytes with (ow,oh) from orc_thumbnail_size. */
+ORC_API int orc_thumbnail_ex(const uint8_t *in, int w, int h, int c, int req_w, int req_h, int filter,
+                             double gap, uint8_t *out)
 {
     int ow, oh;
     if (!orc_thumbnail_size(w, h, req_w, req_h, &ow, &oh)) {
@@ -695,19 +728,28 @@ ORC_API int orc_thumbnail(const uint8_t *in, int w, int h, int c, int req_w, int
         return 0;
     }
     /* Image.resize: factor = int(box_extent / size / reducing_gap) or 1 */
-    int fx = (int)((double)w / ow / 2.0); if (fx < 1) fx = 1;
-    int fy = (int)((double)h / oh / 2.0); if (fy < 1) fy = 1;
+    int fx = 1, fy = 1;
+    if (gap > 0) {
+        fx = (int)((double)w / ow / gap); if (fx < 1) fx = 1;
+        fy = (int)((double)h / oh / gap); if (fy < 1) fy = 1;
+    }
     if (fx > 1 || fy > 1) {
         int rw = (w + fx - 1) / fx, rh = (h + fy - 1) / fy;
         uint8_t *red = (uint8_t *)malloc((size_t)rw * rh * c);
         if (!red) return -1;
         orc_reduce(in, w, h, c, fx, fy, red);
         float bw = (float)((double)w / fx), bh = (float)((double)h / fy);
-        int rc = orc_resize_bicubic(red, rw, rh, c, bw, bh, ow, oh, out);
+        int rc = orc_resize(filter, red, rw, rh, c, bw, bh, ow, oh, out);
         free(red);
         return rc;
     }
-    return orc_resize_bicubic(in, w, h, c, (float)w, (float)h, ow, oh, out);
+    return orc_resize(filter, in, w, h, c, (float)w, (float)h, ow, oh, out);
+}
+
+/* Image.thumbnail((req_w, req_h)) with the defaults BICUBIC / reducing_gap=2.0 (mrc.py:422-428). */
+ORC_API int orc_thumbnail(const uint8_t *in, int w, int h, int c, int req_w, int req_h, uint8_t *out)
+{
+    return orc_thumbnail_ex(in, w, h, c, req_w, req_h, 0, 2.0, out);
 }
 
 /* ------------------------------------------------------------------------- */

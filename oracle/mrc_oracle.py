@@ -239,6 +239,27 @@ def thumbnail(arr, req_w, req_h):
     return out
 
 
+FILTERS = {'bicubic': 0, 'lanczos': 1}
+
+
+def thumbnail_ex(arr, req_w, req_h, resample='bicubic', reducing_gap=2.0):
+    """np.array of Image.fromarray(arr).thumbnail((req_w, req_h), resample=..., reducing_gap=...);
+    reducing_gap=None skips Image.reduce (the page-ingest downsample, recode.py:368-372)."""
+    a = _u8(arr)
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    ow, oh, changed = thumbnail_size(w, h, int(req_w), int(req_h))
+    if not changed:
+        return a.copy()
+    out = np.empty((oh, ow) if a.ndim == 2 else (oh, ow, c), dtype=np.uint8)
+    L = lib()
+    L.orc_thumbnail_ex.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, u8p]
+    rc = L.orc_thumbnail_ex(_p(a, u8p), w, h, c, int(req_w), int(req_h), FILTERS[resample],
+                            float(reducing_gap) if reducing_gap else 0.0, _p(out, u8p))
+    assert rc == 0
+    return out
+
+
 def reduce(arr, fx, fy):
     a = _u8(arr)
     h, w = a.shape[:2]

@@ -141,3 +141,23 @@ def test_thumbnail_geometries_matrix_core_and_fallback(no_mfma, monkeypatch):
         _lib.check(lib.mrchip_thumbnail(ctx.handle, _lib.ptr(np.ascontiguousarray(im)), w, h, c, rw, rh, _lib.ptr(out)))
         exp = O.thumbnail(im, rw, rh)
         assert out.shape == exp.shape and np.array_equal(out, exp), (shape, rw, rh, no_mfma)
+
+
+def test_lanczos_ingest_downsample_matches_pillow_vectors_and_oracle():
+    """recode.py:368-372: image.thumbnail((w/ds, h/ds), resample=Image.LANCZOS, reducing_gap=None) -- the same
+    resample machinery with the Lanczos3 table (matrix-core path up to scale ~3, integer kernels beyond)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lanczos.npz'))
+    for m in z['meta']:
+        i, ds, flt, gap, rw, rh = str(m).split('|')
+        a = z['in_' + i]
+        h, w = a.shape[:2]
+        got = mrc.thumbnail(a, (w / float(ds), h / float(ds)), resample=flt, reducing_gap=None if gap == 'None' else float(gap))
+        assert got.shape == z['out_' + i].shape and np.array_equal(got, z['out_' + i]), m
+    rng = np.random.RandomState(8)
+    for shape, ds in [((1000, 1500, 3), 2), ((999, 1333), 3), ((800, 1200, 3), 4), ((517, 333, 3), 5.5), ((100, 3000, 3), 2)]:
+        a = rng.randint(0, 256, shape).astype(np.uint8)
+        h, w = shape[:2]
+        got = mrc.thumbnail(a, (w / ds, h / ds), resample='lanczos', reducing_gap=None)
+        exp = O.thumbnail_ex(a, int(w / ds), int(h / ds), 'lanczos', None)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (shape, ds)

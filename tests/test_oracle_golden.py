@@ -147,3 +147,14 @@ def test_config1_digest():
     assert sha(img) == d['in']
     t = O.threshold_image(img, 124)
     assert sha(t) == d['out'] and int(t.sum()) == d['sum']
+
+
+def test_lanczos_ingest_downsample_against_pillow_vectors():
+    """tests/golden/lanczos.npz holds what the real Pillow returned for
+    image.thumbnail((w/ds, h/ds), resample=LANCZOS, reducing_gap=None) (recode.py:368-372) and variants."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lanczos.npz'))
+    for m in z['meta']:
+        i, ds, flt, gap, rw, rh = str(m).split('|')
+        got = O.thumbnail_ex(z['in_' + i], int(rw), int(rh), flt, None if gap == 'None' else float(gap))
+        assert got.shape == z['out_' + i].shape and np.array_equal(got, z['out_' + i]), m
