@@ -49,6 +49,8 @@ struct mrchip_batch {
     DevBuf gtmp;  int gtmp_pitch = 0;  size_t gtmp_stride = 0;     // float32 scratch of the blur
     DevBuf sig_scratch;  size_t sig_stride = 0;
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
+    std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
+    hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
     DevBuf packed;  int packed_valid = 0;     // 1-bpp copy of the finished masks (made on first request)
     size_t dn_stride = 0, th_bytes = 0;
     ThumbPlan plan[2];
@@ -133,6 +135,7 @@ MRCHIP_EXPORT void mrchip_batch_destroy(mrchip_batch *b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->s);
     if (b->hctrl) (void)hipHostFree(b->hctrl);
+    if (b->box_ev) (void)hipEventDestroy(b->box_ev);
     delete b;
 }
 
@@ -182,7 +185,8 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
     const int w = b->w, h = b->h, N = b->n;
     b->window = window;
     if (b->c == 3) TRY(launch_luma601(ctx, s, b->img.pl, b->gray_own.pl, w, h, N));                       // mrc.py:361
-    HIP_TRY(hipMemsetAsync(b->mask.pl.p, 0, b->mask.pl.stride * (size_t)(N - 1) + (size_t)b->mask.pl.pitch * h, s)); // :367
+    // mask_arr = zeros (mrc.py:367) is never materialised: the page threshold is stored first and the hOCR
+    // boxes are OR-ed on top (mask_finish), which is the same set of pixels as commit-then-OR (mrc.py:266, 329)
     // ---- hOCR boxes of all pages: both polarities + counts ----
     b->boxes.clear();
     b->first_box.assign(N + 1, 0);
@@ -265,18 +269,22 @@ MRCHIP_EXPORT int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est) {
 
 // decisions (mrc.py:240-263, host float64 like the reference) + ordered commit (mrc.py:266).
 // Boxes whose ratios do not settle the polarity need mean_estimate_sigma of both bool thresholds
-// (mrc.py:253-254): all of them, over the whole batch, run as ONE job list (float64 path) and
-// one synchronisation.
-static int decide_and_commit(mrchip_batch *b) {
+// (mrc.py:253-254): all of them, over the whole batch, run as ONE job list (float64 path).
+// Phase 1 (box_decisions_begin) settles what the ratios settle and enqueues those jobs + the copy of
+// their results, marked by an event; phase 2 (box_decisions_commit) waits for the event only -- the
+// caller puts independent work (blur, page threshold) on the stream in between -- and commits.
+static int box_decisions_begin(mrchip_batch *b) {
     const int nb = (int)b->boxes.size();
+    b->need.clear();
     if (nb == 0) return 0;
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
     const CtrlLayout L(b->n, nb);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
     const unsigned *counts = reinterpret_cast<const unsigned *>(b->hctrl + L.counts);
-    std::vector<int> need;          // boxes on the sigma path
-    std::vector<double> ratio(nb), inv_ratio(nb);
+    std::vector<int> &need = b->need;          // boxes on the sigma path
+    std::vector<double> &ratio = b->ratio, &inv_ratio = b->inv_ratio;
+    ratio.assign(nb, 0.0); inv_ratio.assign(nb, 0.0);
     for (int i = 0; i < nb; i++) {
         BoxInfo &bi = b->boxes[i];
         const double size = (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
@@ -297,8 +305,11 @@ static int decide_and_commit(mrchip_batch *b) {
             offs[k] = total;
             total += sigma_scratch_bytes(bi.r - bi.l, bi.b - bi.t, 1);
         }
-        HIP_TRY(hipStreamSynchronize(s));
-        TRY(b->box_sig_scratch.alloc(ctx, total + 256));
+        if (total + 256 > b->box_sig_cap) {          // grow-only: no synchronisation in the steady state
+            HIP_TRY(hipStreamSynchronize(s));
+            TRY(b->box_sig_scratch.alloc(ctx, total + total / 4 + 256));
+            b->box_sig_cap = total + total / 4 + 256;
+        }
         SigJob *hj = reinterpret_cast<SigJob *>(b->hctrl + L.boxsigjobs);
         SigJob *dj = reinterpret_cast<SigJob *>(dctrl + L.boxsigjobs);
         for (int k = 0; k < nj; k++) {
@@ -313,7 +324,25 @@ static int decide_and_commit(mrchip_batch *b) {
         HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(SigJob), hipMemcpyHostToDevice, s));
         TRY(launch_estimate_sigma_jobs(ctx, s, hj, dj, nj, 1, dsig));
         HIP_TRY(hipMemcpyAsync(b->hctrl + L.box_sigma, dsig, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (!b->box_ev) HIP_TRY(hipEventCreateWithFlags(&b->box_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->box_ev, s));
+    }
+    return 0;
+}
+
+// or_mode: OR the decided thresholds into a mask that already holds the page threshold (batch
+// pipeline) instead of assigning them (mrc.create_hocr_mask on a caller's mask, mrc.py:266)
+static int box_decisions_commit(mrchip_batch *b, int or_mode) {
+    const int nb = (int)b->boxes.size();
+    if (nb == 0) return 0;
+    mrchip_ctx *ctx = b->ctx;
+    hipStream_t s = b->s;
+    const CtrlLayout L(b->n, nb);
+    unsigned char *dctrl = b->ctrl.as<unsigned char>();
+    const std::vector<int> &need = b->need;
+    const std::vector<double> &ratio = b->ratio, &inv_ratio = b->inv_ratio;
+    if (!need.empty()) {
+        HIP_TRY(hipEventSynchronize(b->box_ev));
         const double *hs = reinterpret_cast<const double *>(b->hctrl + L.box_sigma);
         for (size_t q = 0; q < need.size(); q++) {
             const int i = need[q];
@@ -347,7 +376,12 @@ static int decide_and_commit(mrchip_batch *b) {
         if (bi.decision) area += (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
     }
     HIP_TRY(hipMemcpyAsync(db, hb, (size_t)nb * sizeof(HocrBox), hipMemcpyHostToDevice, s));
-    return launch_hocr_commit(ctx, s, db, nb, maxw, maxh, area);
+    return launch_hocr_commit(ctx, s, db, nb, maxw, maxh, area, or_mode);
+}
+
+static int decide_and_commit(mrchip_batch *b) {       // assignment semantics, one go (mrchip_hocr_mask)
+    TRY(box_decisions_begin(b));
+    return box_decisions_commit(b, 0);
 }
 
 MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weights, const int *radius, int denoise_fast) {
@@ -359,7 +393,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     const int w = b->w, h = b->h, N = b->n, nb = (int)b->boxes.size();
     const CtrlLayout L(N, nb);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
-    TRY(decide_and_commit(b));
+    TRY(box_decisions_begin(b));          // box sigma jobs go first; their results are awaited after the page threshold is queued
     // ---- create_threshold_mask (mrc.py:300-329) ----
     GaussW *hg = reinterpret_cast<GaussW *>(b->hctrl + L.gauss);
     bool any_blur = false;
@@ -406,7 +440,8 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
-    TRY(launch_sauvola_dev(ctx, s, hj, dj, N, b->window, b->window, 0.34, 128.0, SAUVOLA_INVERT | SAUVOLA_OR)); // :325-329
+    TRY(launch_sauvola_dev(ctx, s, hj, dj, N, b->window, b->window, 0.34, 128.0, SAUVOLA_INVERT));   // :325-329 (stored, not OR-ed)
+    TRY(box_decisions_commit(b, 1));      // mrc.py:240-266 on top: mask = page threshold | box thresholds
     if (denoise_fast)
         TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N));  // :388
     b->state = 4;

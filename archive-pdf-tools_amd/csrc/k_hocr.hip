@@ -6,7 +6,7 @@
 
 namespace mrchip {
 
-__global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes) {
+__global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, int or_mode) {
     const int b = blockIdx.z;
     const HocrBox B = boxes[b];
     if (B.decision == 0) return;
@@ -41,20 +41,28 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes) 
         if (!keep) continue;
         const unsigned v = *reinterpret_cast<const unsigned *>(th + (ptrdiff_t)y * B.pitch + (xa - B.l));
         uint8_t *mp = mask + (size_t)py * mpitch + xa;
-        if (keep == 0xffffffffu) *reinterpret_cast<unsigned *>(mp) = v;
-        else {      // partial dword: byte stores, so that a neighbouring box's bytes are never rewritten
+        // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel
+        // has exactly one owner (box, lane), so the read-modify-write is race-free
+        if (keep == 0xffffffffu) {
+            unsigned *mq = reinterpret_cast<unsigned *>(mp);
+            *mq = or_mode ? (*mq | v) : v;
+        } else {      // partial dword: byte accesses, so that a neighbouring box's bytes are never rewritten
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if ((keep >> (8 * i)) & 0xffu) mp[i] = (uint8_t)(v >> (8 * i));
+                if ((keep >> (8 * i)) & 0xffu) {
+                    const uint8_t bv = (uint8_t)(v >> (8 * i));
+                    mp[i] = or_mode ? (uint8_t)(mp[i] | bv) : bv;
+                }
         }
     }
 }
 
-int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area) {
+int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
+                       int or_mode) {
     if (nb <= 0) return 0;
     dim3 grid(cdiv(cdiv(maxw + 3, 4), 256), std::min(maxh, 64), nb);
-    LAUNCH(ctx, s, "hocr_commit", 2.0 * area,
-           hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes));
+    LAUNCH(ctx, s, "hocr_commit", (or_mode ? 3.0 : 2.0) * area,
+           hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes, or_mode));
     return 0;
 }
 

@@ -205,7 +205,8 @@ struct HocrBox {
     int page_end;            // index one past the last box of the same page
     int overlapped;          // a later box of the page with a decision intersects this one
 };
-int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area);
+int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
+                       int or_mode);
 
 constexpr int THUMB_MAXK = 20;
 // thumbnail plan: host-side size rule + fixed-point coefficient tables
