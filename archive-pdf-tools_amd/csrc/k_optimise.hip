@@ -526,7 +526,19 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             const int x = x0 + i;
             const int xs = max(0, x - n);
             int fsum[C], fcnt;
-            if constexpr (C == 3) {
+            if constexpr (NH == 1 && NCT >= 0 && NCT <= 7) {
+                // FIR + IIR window sums stay below 2^16 for n <= 7 (14*14*255 + 49*255): add the packed
+                // pairs first, then split (the conversions take the 16-bit halves directly)
+                Ent T = aL;
+                eadd(T, aI);
+                if constexpr (C == 3) {
+                    fsum[0] = (int)(T.d[0] & 0xffffu); fsum[1] = (int)(T.d[0] >> 16);
+                    fsum[2] = (int)(T.d[1] & 0xffffu); fcnt = (int)(T.d[1] >> 16);     // the IIR entry has no count half
+                } else {
+                    // gray: FIR {f | cnt<<16}, IIR {i} (a full dword, may exceed 16 bits only for n > 7)
+                    fsum[0] = (int)(T.d[0] & 0xffffu); fcnt = (int)(T.d[0] >> 16);
+                }
+            } else if constexpr (C == 3) {
                 fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)(aI.d[0] & 0xffffu);
                 fsum[1] = (int)(aL.d[0] >> 16) + (int)(aI.d[0] >> 16);
                 fsum[2] = (int)(aL.d[1] & 0xffffu) + (int)(aI.d[1] & 0xffffu);
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const OptJob J = jobs[blockIdx.x];
     // wave-uniform dispatch on the job's n_size: the reference's two values get unrolled bodies
-    if (J.n == 3) optimise_packed_rows<C, NH, 3, DB>(J, smem);            // fg, mrc.py:413/415
+    if (J.n == 3) optimise_packed_rows<C, 1, 3, DB>(J, smem);             // fg, mrc.py:413/415 (one accumulator: n <= 8)
     else if (J.n == 10) {
         if constexpr (NH == 2) optimise_packed_rows<C, NH, 10, DB>(J, smem);   // bg, mrc.py:447/449
         else optimise_packed_rows<C, NH, -1, DB>(J, smem);

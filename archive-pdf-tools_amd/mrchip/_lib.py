@@ -7,6 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmrchip.so')
+if os.environ.get('MRCHIP_LIB'):        # A/B runs of two builds in one process tree (tools/)
+    LIB_PATH = os.environ['MRCHIP_LIB']
 
 MAX_TAPS = 128        # MRCHIP_MAX_TAPS
 u8p = C.POINTER(C.c_uint8)

@@ -108,8 +108,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--pages', type=int, default=256, help='pages per GPU per step')
-    ap.add_argument('--inflight', type=int, default=2, help='device batches in flight per GPU (one HIP stream each)')
+    ap.add_argument('--pages', type=int, default=384, help='pages per GPU per step')
+    ap.add_argument('--inflight', type=int, default=3, help='device batches in flight per GPU (one HIP stream each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed parity / PCIe-inclusive section (profiling runs)')
     a = ap.parse_args()
