@@ -302,6 +302,28 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
 }
 
 
+// 16-bit halves added straight out of the packed pairs (SDWA operand selects): no shift / mask first
+__device__ __forceinline__ unsigned add_w0w0(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned add_w1w1(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned add_dw0(unsigned a, unsigned b) {      // a + (b & 0xffff)
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned add_dw1(unsigned a, unsigned b) {      // a + (b >> 16)
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Packed variant (the one the reference's two call sites use: n=3 and n=10).
 // Per column the running sums live in the registers in the very format of the LDS rows:
@@ -538,15 +560,17 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                     // gray: FIR {f | cnt<<16}, IIR {i} (a full dword, may exceed 16 bits only for n > 7)
                     fsum[0] = (int)(T.d[0] & 0xffffu); fcnt = (int)(T.d[0] >> 16);
                 }
+            } else if constexpr (C == 3 && NH == 2) {
+                // three packed pairs per sum (left half, right half, IIR): the halves are added as they are
+                fsum[0] = (int)add_dw0(add_w0w0(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[1] = (int)add_dw1(add_w1w1(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[2] = (int)add_dw0(add_w0w0(aL.d[1], aR.d[1]), aI.d[1]);
+                fcnt = (int)add_w1w1(aL.d[1], aR.d[1]);
             } else if constexpr (C == 3) {
                 fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)(aI.d[0] & 0xffffu);
                 fsum[1] = (int)(aL.d[0] >> 16) + (int)(aI.d[0] >> 16);
                 fsum[2] = (int)(aL.d[1] & 0xffffu) + (int)(aI.d[1] & 0xffffu);
                 fcnt = (int)(aL.d[1] >> 16);
-                if constexpr (NH == 2) {
-                    fsum[0] += (int)(aR.d[0] & 0xffffu); fsum[1] += (int)(aR.d[0] >> 16);
-                    fsum[2] += (int)(aR.d[1] & 0xffffu); fcnt += (int)(aR.d[1] >> 16);
-                }
             } else {
                 fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)aI.d[0];
                 fcnt = (int)(aL.d[0] >> 16);
