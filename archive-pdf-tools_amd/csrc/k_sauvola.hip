@@ -242,8 +242,23 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         gload(y - o + PF, ql[PF - 1]);
         gload(y + PF, qc[PF - 1]);
         mload(y + PF, qm[PF - 1]);
-        if (y + u < h) acc_row_m(ev, true);
-        if (y - o >= 0) acc_row_m(lv, false);
+        // entering row y+u and leaving row y-o together: with d = pe - pl and t = pe + pl per column,
+        // S += d and Q += pe^2 - pl^2 = d * t (one signed 24-bit multiply-add); a row outside the image
+        // contributes zeros (wave-uniform selects)
+        {
+            const bool has_e = y + u < h, has_l = y - o >= 0;
+#pragma unroll
+            for (int q = 0; q < KD; q++) {
+                const unsigned em = has_e ? (ev[q] & vmask[q]) : 0u, lm = has_l ? (lv[q] & vmask[q]) : 0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int pe = (int)((em >> (8 * b)) & 0xffu), pl = (int)((lm >> (8 * b)) & 0xffu);
+                    const int d = pe - pl, t = pe + pl;
+                    cs[4 * q + b] += (unsigned)d;
+                    cq[4 * q + b] += (unsigned)__mul24(d, t);
+                }
+            }
+        }
         const int nrows = min(y + u, h - 1) - max(y - o, -1);
 
         // exclusive prefix over the strip's columns
