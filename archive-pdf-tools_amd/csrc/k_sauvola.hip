@@ -70,42 +70,31 @@ __device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) 
     if constexpr (K == 16) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 }
 
-// floor(N / c) for c >= 1: fp32 estimate (|error| < 1 for N < 2^32, quotient < 2^17) + one exact
-// correction step in wrap-around 32-bit arithmetic.  rc = 1/c to 1 ulp.
-__device__ __forceinline__ unsigned div_exact(unsigned N, unsigned c, float rc) {
-    unsigned q = (unsigned)((float)N * rc);
-    int rem = (int)(N - __umul24(q, c));       // q < 2^17, c < 2^17: the 24-bit multiply is exact mod 2^32
-    q += (rem >= (int)c) ? 1u : 0u;
-    q -= (rem < 0) ? 1u : 0u;
-    return q;
-}
-
-// the reference's decision (pyx:143-153) for one pixel; returns `form`.  mean and Q/count are the
-// truncated integer quotients (cdivision), everything after that is fp64 in the reference's order.
-__device__ __forceinline__ bool sauvola_form(unsigned mean_i, unsigned qd_i, unsigned px, bool kpos, double km1, double k2) {
-    const unsigned mm_i = __umul24(mean_i, mean_i);        // < 2^16
-    const double mean = (double)mean_i;
-    const double mm = (double)mm_i;                       // == mean*mean exactly
-    const double variance = (double)(int)(qd_i - mm_i);   // == (double)qd - mean*mean exactly (integers)
+// The reference's decision (pyx:143-153) for one pixel; returns `form`.  The whole of it runs in
+// fp64, divisions included.  floor(N / c) for integers N < 2^32, 1 <= c < 2^17:
+// (N + 0.5) / c is at least 0.5/c away from every integer while the fma below (N exact, rc = 1/c to
+// a few ulp, one rounding) is off by less than (N/c) * 2^-50 < 0.5/c, so the floor is exact.  mean
+// and Q/count are then integer-valued doubles -- the very values the reference converts from its
+// truncated integer quotients (pyx:144-145) -- mean*mean and the variance are exact, and the rest
+// is the reference's own operation sequence.  Cheaper than integer quotients + conversions:
+// 3 conversions instead of 4 and no correction steps.
+__device__ __forceinline__ bool sauvola_form_d(unsigned S, unsigned Q, unsigned px, double rc, double hrc, bool kpos,
+                                               double km1, double k2) {
+    const double mean = __builtin_floor(__builtin_fma((double)S, rc, hrc));
+    const double qd = __builtin_floor(__builtin_fma((double)Q, rc, hrc));
+    const double mm = __dmul_rn(mean, mean);
+    const double variance = __dadd_rn(qd, -mm);
     const double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
     const double lhs = __dmul_rn(tmp, tmp);
     const double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
     const bool neg = tmp <= 0;
-    // k >= 0: neg || lhs <= rhs;  k < 0: neg && lhs >= rhs   (pyx:146-151), branch-free
     return kpos ? (neg || (lhs <= rhs)) : (neg && (lhs >= rhs));
-}
-
-// floor(S / c) without a correction step when S < 2^20: floor((S + 0.5) / c) == floor(S / c) for
-// integers, (S + 0.5)/c is at least 0.5/c away from an integer, and the fp32 evaluation (S exact,
-// rc and the fma one rounding each) is off by less than q * 2^-22 < 0.5/c  <=>  S < 2^21.
-__device__ __forceinline__ unsigned mean_small(unsigned S, float rc, float hrc) {
-    return (unsigned)__builtin_fmaf((float)S, rc, hrc);
 }
 
 // Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
 // (wh-1)-row warm-up).  (An LDS ring of the last wh rows was tried: it removes the re-reads but
 // caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
-template <int K, bool MULTI, bool SMALL>
+template <int K, bool MULTI>
 __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
     constexpr int KD = K / 4;
@@ -278,7 +267,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
 
         // wave-uniform count / reciprocal when every output of the strip has the full window width
         const unsigned ucount = (unsigned)(P.ww * nrows);
-        const float urc = __builtin_amdgcn_rcpf((float)ucount);
+        const double urcd = __builtin_amdgcn_rcp((double)ucount), uhrcd = 0.5 * urcd;
 
         unsigned outa[KD], outb[KD];
 #pragma unroll
@@ -296,17 +285,15 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             const unsigned S = EsBuf[ia] - EsBuf[ib];
             const unsigned Q = EqBuf[ia] - EqBuf[ib];
             unsigned count = ucount;
-            float rc = urc;
+            double rcd = urcd, hrcd = uhrcd;
             if (!full_cols) {
                 const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
                 count = (unsigned)max(ncols * nrows, 1);
-                rc = __builtin_amdgcn_rcpf((float)count);
+                rcd = __builtin_amdgcn_rcp((double)count);
+                hrcd = 0.5 * rcd;
             }
             const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
-            const float hrc = 0.5f * rc;
-            const unsigned mean_i = SMALL ? mean_small(S, rc, hrc) : div_exact(S, count, rc);   // pyx:144 (cdivision)
-            const unsigned qd_i = div_exact(Q, count, rc);              // pyx:145
-            const bool form = sauvola_form(mean_i, qd_i, px, kpos, P.km1, P.k2);
+            const bool form = sauvola_form_d(S, Q, px, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
             const unsigned bit = valid ? ((form ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;   // pyx:153 (+ mrc.py:85)
             outa[i / 4] |= bit << (8 * (i & 3));
             ones_a += bit;
@@ -314,8 +301,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 // the same window on the image 255-p (mrc.py:224, 235)
                 const unsigned Si = __umul24(255u, count) - S;
                 const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
-                const unsigned mi = SMALL ? mean_small(Si, rc, hrc) : div_exact(Si, count, rc);
-                const bool fi = sauvola_form(mi, div_exact(Qi, count, rc), 255u - px, kpos, P.km1, P.k2);
+                const bool fi = sauvola_form_d(Si, Qi, 255u - px, rcd, hrcd, kpos, P.km1, P.k2);
                 const unsigned bi = valid ? ((fi ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;
                 outb[i / 4] |= bi << (8 * (i & 3));
                 ones_b += bi;
@@ -381,15 +367,13 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     if (const char *e = getenv("MRCHIP_SAUVOLA_TH")) { int v = atoi(e); if (v >= 8) th = v; }   // tuning knob
     P.th = th;
     dim3 grid(strips, cdiv(maxh, th), njobs);
-    // window sums below 2^20: the mean's division needs no correction step (mean_small)
-    const bool small_s = 255ll * P.ww * P.wh < (1ll << 20);
     const char *nm = (njobs == 1 && !d_jobs) ? "sauvola" : (h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola");
-#define SV_LAUNCH(MULTI, SMALL)                                                                                   \
-    LAUNCH(ctx, s, nm, alg_bytes,                                                                                 \
-           hipLaunchKernelGGL((sauvola_kernel<K, MULTI, SMALL>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P))
-    if (njobs == 1 && !d_jobs) { if (small_s) SV_LAUNCH(false, true); else SV_LAUNCH(false, false); }
-    else { if (small_s) SV_LAUNCH(true, true); else SV_LAUNCH(true, false); }
-#undef SV_LAUNCH
+    if (njobs == 1 && !d_jobs)
+        LAUNCH(ctx, s, nm, alg_bytes,
+               hipLaunchKernelGGL((sauvola_kernel<K, false>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
+    else
+        LAUNCH(ctx, s, nm, alg_bytes,
+               hipLaunchKernelGGL((sauvola_kernel<K, true>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
     return 0;
 }
 
