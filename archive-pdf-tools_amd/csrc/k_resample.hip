@@ -414,6 +414,103 @@ __global__ __launch_bounds__(64 * WPB) void resize_mm_kernel(const uint8_t *src,
     }
 }
 
+// Workgroup-wide variant of the memory side: the 16 tiles of a workgroup read overlapping 128-byte
+// windows of the same 16 lines (tiles are 48 input bytes apart at scale 3), so the workgroup loads
+// the union once -- one contiguous span per line, lanes along it -- into a double-buffered LDS
+// panel (one barrier per line group) and every wave takes its operands from there.  2.4x fewer
+// load instructions, no overlap re-fetched.  Needs 16-byte aligned tile bases (build_mm) and a
+// span of at most 1024 bytes.
+constexpr int PNW = 16;         // waves = tiles per workgroup
+template <int KB>
+__global__ __launch_bounds__(64 * PNW) void resize_mm_panel_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
+                                                                   uint8_t *dst, int dpitch, size_t dstride, int nout, int ntiles,
+                                                                   const int32_t *kbase, const int32_t *bias, const v4i *btab,
+                                                                   int quads_per_wave, int pad_ok, int gx, int gy, int gz,
+                                                                   int panel_w, int pws) {
+    const int total = gx * gy * gz, per = (total + 7) >> 3;            // XCD-contiguous work order (see above)
+    const int V = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (V >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int bx = V % gx, by = (V / gx) % gy, bz = V / (gx * gy);
+    constexpr int OSTR = 80;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *inP = smem;                                        // [2][16][pws]
+    unsigned char *outP = smem + 2 * 16 * pws;                        // [PNW][16][OSTR]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile0 = bx * PNW, tile = tile0 + wv;
+    const bool active = tile < ntiles;
+    src += (size_t)bz * sstride;
+    dst += (size_t)bz * dstride;
+    const int nn = lane & 15, kq = lane >> 4;
+    v4i B[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) B[kb][d] = active ? btab[((size_t)(tile * KB + kb) * 3 + d) * 64 + lane] : (v4i){0, 0, 0, 0};
+    const int bs = active ? bias[tile * 16 + nn] : 0;
+    const int kbP = kbase[tile0];                                     // first byte of the panel
+    const int koff = active ? kbase[tile] - kbP : 0;                  // multiple of 16
+    const int nquads = (nlines + 63) >> 6;
+    const int q0 = by * quads_per_wave, q1 = min(nquads, q0 + quads_per_wave);
+    if (q0 >= q1) return;                                             // uniform over the workgroup
+    unsigned char *op = outP + wv * 16 * OSTR;
+    const int cpl = panel_w >> 4;                                     // 16-byte chunks per line
+    const int ld_line = tid / cpl, ld_chunk = tid - ld_line * cpl;
+    const bool loader = tid < 16 * cpl;
+
+    auto gload = [&](int g) -> v4i {
+        const int line = min(g * 16 + ld_line, nlines - 1);           // past the end: repeat the last line (never stored)
+        return *reinterpret_cast<const v4i_u1 *>(src + (size_t)line * spitch + kbP + ld_chunk * 16);
+    };
+    const int g_end = q1 * 4;
+    v4i stage[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (loader) { stage[0] = gload(q0 * 4); stage[1] = gload(min(q0 * 4 + 1, g_end - 1)); }
+    for (int q = q0; q < q1; q++) {
+#pragma unroll
+    for (int gi = 0; gi < 4; gi++) {
+        const int g = q * 4 + gi;
+        unsigned char *ip = inP + (gi & 1) * 16 * pws;
+        if (loader) {
+            *reinterpret_cast<v4i *>(ip + ld_line * pws + ld_chunk * 16) = stage[gi & 1] ^ (int)0x80808080;   // px - 128
+            stage[gi & 1] = gload(min(g + 2, g_end - 1));             // group g+2 in flight during the MFMAs
+        }
+        // one barrier per group: buffer gi&1 is rewritten two groups later, after the barrier of group
+        // g+1, which every wave reaches only when it is done reading this one
+        lds_barrier();
+        if (active) {
+            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) {
+                const v4i x = *reinterpret_cast<const v4i *>(ip + nn * pws + koff + kb * 64 + kq * 16);
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][2], acc2, 0, 0, 0);
+            }
+            unsigned packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bs);
+                int qv = min(max(ss >> 22, 0), 255);                         // Resample.c clip8
+                asm volatile("" : "+v"(qv));                                 // no v_ashr_pk_u8_i32 (see resize_mm_kernel)
+                packed |= (unsigned)qv << (8 * i);
+            }
+            *reinterpret_cast<unsigned *>(op + nn * OSTR + gi * 16 + kq * 4) = packed;
+            if (gi == 3) {
+                lds_wave_sync();
+                const int n2 = tile * 16 + (lane >> 2), c16 = (lane & 3) * 16;
+                const v4i v = *reinterpret_cast<const v4i *>(op + (lane >> 2) * OSTR + c16);
+                const int line0 = q * 64 + c16;
+                if (n2 < nout) {
+                    uint8_t *o = dst + (size_t)n2 * dpitch + line0;
+                    if (pad_ok || line0 + 16 <= nlines) *reinterpret_cast<v4i_u1 *>(o) = v;
+                    else
+                        for (int i = 0; line0 + i < nlines; i++) o[i] = (uint8_t)((unsigned)v[i >> 2] >> (8 * (i & 3)));
+                }
+            }
+        }
+    }
+    }
+}
+
 // B operand, kbase and bias of one pass.  cs: byte stride between the taps of one output (the
 // channel count for the horizontal pass over interleaved pixels, 1 for the vertical pass).
 static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32_t> &kk, int ksize, int nout_px, int cs,
@@ -452,10 +549,18 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
             }
             if (hi >= 0) KB1 = std::max(KB1, cdiv(hi - lo + 1, 64));
         }
+        t.kalign = kalign;
         if (KB == KB1) break;
     }
     if (KB > 2) return false;
     t.KB = KB;
+    // span of the 16 tiles of a workgroup (panel kernel)
+    t.panel_w = 0;
+    for (int T0 = 0; T0 < t.ntiles; T0 += 16) {
+        const int T1 = std::min(T0 + 15, t.ntiles - 1);
+        t.panel_w = std::max(t.panel_w, t.kbase[T1] + KB * 64 - t.kbase[T0]);
+    }
+    t.panel_w = round_up(t.panel_w, 16);
     t.b.assign((size_t)t.ntiles * KB * 3 * 1024, 0);
     for (int T = 0; T < t.ntiles; T++)
         for (int nn = 0; nn < 16; nn++) {
@@ -588,11 +693,27 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
             const Plane in = pass == 0 ? cur : scratch2, out = pass == 0 ? scratch2 : dst;
             const int nlines = pass == 0 ? ch_ : p.mmh.nout;
             static const int wpb = getenv("MRCHIP_MM_WPB") ? atoi(getenv("MRCHIP_MM_WPB")) : 16;
-            const int gx = cdiv(M.ntiles, wpb), gy = cdiv(cdiv(nlines, 64), qpw);
+            static const int no_panel = getenv("MRCHIP_MM_NO_PANEL") ? 1 : 0;
+            const bool panel = !no_panel && M.kalign == 16 && M.panel_w <= 1024;
+            const int wg_tiles = panel ? PNW : wpb;
+            const int gx = cdiv(M.ntiles, wg_tiles), gy = cdiv(cdiv(nlines, 64), qpw);
             const dim3 grid(round_up(gx * gy * npages, 8));
             const double a = (pass == 0 && !red) ? alg : 0.0;
             const char *nm = pass == 0 ? "thumb_resize_h" : "thumb_resize_v";
             const v4i *bt = reinterpret_cast<const v4i *>(tb + p.off_mm[pass][2]);
+            if (panel) {
+                int pws = M.panel_w + 16;
+                if (((pws >> 4) & 1) == 0) pws += 16;          // odd number of 16-byte units per row: conflict-free operand reads
+                const size_t lds = (size_t)2 * 16 * pws + (size_t)PNW * 16 * 80;
+#define MMP_LAUNCH(KBB)                                                                                                   \
+    LAUNCH(ctx, s, nm, a,                                                                                                 \
+           hipLaunchKernelGGL((resize_mm_panel_kernel<KBB>), grid, dim3(64 * PNW), lds, s, in.p, in.pitch, in.stride, nlines, \
+                              out.p, out.pitch, out.stride, M.nout, M.ntiles, tptr(p.off_mm[pass][0]),                     \
+                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages, M.panel_w, pws))
+                if (M.KB == 1) MMP_LAUNCH(1); else MMP_LAUNCH(2);
+#undef MMP_LAUNCH
+                continue;
+            }
 #define MM_LAUNCH(KBB, WW)                                                                                             \
     LAUNCH(ctx, s, nm, a,                                                                                              \
            hipLaunchKernelGGL((resize_mm_kernel<KBB, WW>), grid, dim3(64 * WW), 0, s, in.p, in.pitch, in.stride, nlines, \

@@ -223,7 +223,10 @@ struct ThumbPlan {
     // matrix.  Per tile of 16 outputs: first input byte (kbase), per output the constant term
     // (bias), and the MFMA B operand (KB blocks of 64 input bytes x 3 balanced base-256 digits of
     // the 22-bit coefficients, already in lane order).
-    struct Mm { int ntiles = 0, KB = 0, nout = 0; std::vector<int32_t> kbase, bias; std::vector<unsigned char> b; };
+    struct Mm {
+        int ntiles = 0, KB = 0, nout = 0, kalign = 1, panel_w = 0;   // panel_w: input bytes spanned by 16 consecutive tiles
+        std::vector<int32_t> kbase, bias; std::vector<unsigned char> b;
+    };
     Mm mmh, mmv;
     int mm_ok = 0;            // both passes present and each 16-output tile spans <= 128 input bytes
     // every table in one blob (what the device copy holds), byte offsets of the parts
