@@ -197,6 +197,20 @@ def main():
 
     # untimed: parity evidence + PCIe-inclusive drop-in rate on rank 0
     extra = {}
+    prof_iso = None
+    if rank == 0 and not a.no_extras and nb > 1:
+        # the timed region runs `nb` batches concurrently, so a launch's HIP-event duration there includes the
+        # time it shares the chip with other streams; the same batches one at a time give the kernels' own rates
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(2):
+            for bt in batches:
+                bt.mask_begin(window)
+                bt.mask_finish(bt.sigmas(), True)
+                bt.layers(None, BG_DOWNSAMPLE)
+                ctx.sync()
+        prof_iso = ctx.prof_report()
+        ctx.prof_enable(False)
     if rank == 0 and not a.no_extras:
         mask = batch.download_mask(0)
         try:
@@ -218,7 +232,7 @@ def main():
 
     total_pages = a.pages * a.steps * world
     value = total_pages / dt
-    def roofline_of(name):
+    def roofline_of(name, prof=prof):
         r = prof[name]
         ms = r['ms'] / r['launches']
         alg = r['alg_bytes'] / r['launches']
@@ -247,6 +261,15 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1]['ms']) if prof else None
     roof = roofline_of(dom[0]) if dom else None
     sauvola_roof = roofline_of('sauvola') if 'sauvola' in prof else None
+    if prof_iso and dom:
+        iso = roofline_of(dom[0], prof_iso)
+        roof['isolated'] = {'achieved': iso['achieved'], 'frac': iso['frac'], 'avg_launch_ms': iso['avg_launch_ms'],
+                            'note': 'same batches run one at a time after the timed region (no other stream on the chip)'}
+        roof['note'] = ('%d batches share the chip in the timed region: avg_launch_ms / achieved / frac are per-launch '
+                        'figures under that concurrency' % nb)
+        if sauvola_roof and 'sauvola' in prof_iso:
+            si = roofline_of('sauvola', prof_iso)
+            sauvola_roof['isolated'] = {'achieved': si['achieved'], 'frac': si['frac'], 'avg_launch_ms': si['avg_launch_ms']}
     kernels = {k: {'ms_per_launch': round(v['ms'] / v['launches'], 4), 'launches': v['launches'],
                    'alg_GBps': round(v['alg_bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in sorted(prof.items())}
     if rank == 0:
