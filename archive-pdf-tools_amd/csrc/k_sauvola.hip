@@ -405,7 +405,11 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
         }
     }
     static const int force_k = getenv("MRCHIP_SAUVOLA_K") ? atoi(getenv("MRCHIP_SAUVOLA_K")) : 0;   // tuning knob
-    if (ww <= 120 && force_k != 8) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    // 8 columns per lane halve the strip halo (452 of 512 columns are outputs instead of 200 of 256) at the
+    // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops
+    const bool page_like = maxw >= 1024 && maxh >= 256;
+    if (ww <= 120 && force_k != 8 && !(page_like && force_k != 4))
+        return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     if (ww <= 360) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     return launch_k<16>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
 }
