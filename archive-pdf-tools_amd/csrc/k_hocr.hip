@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
     if (B.decision == 0) return;
     uint8_t *mask = B.mask;
     const int mpitch = B.mpitch, nb = B.page_end;
-    const int bw = B.r - B.l, bh = B.b - B.t;
+    const int bh = B.b - B.t;
     // one lane per 4 pixels, dword-aligned in the MASK's coordinates (the box scratch has the
     // same column phase mod 16, so its dwords line up too)
     const int xa = (B.l & ~3) + (blockIdx.x * 256 + threadIdx.x) * 4;     // absolute column of the dword

@@ -187,30 +187,13 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
     // three register queues, PF rows deep: entering rows y+u, leaving rows y-o, centre rows y.
     // Every address is known in advance, so the loads run PF rows ahead of their use and the
     // serial chain of a row never waits for memory (leaving / centre rows come back from L2/MALL).
-    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD], qm[PF][KD];
+    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD];
     const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
-    const bool do_or = (P.flags & SAUVOLA_OR) != 0;
-    // OR mode (mask |= thr, mrc.py:329): the destination row is prefetched like the sources
-    typedef const unsigned __attribute__((address_space(1))) *gc_u32q;
-    const bool dst_al = ((reinterpret_cast<uintptr_t>(job.dst) + (intptr_t)c0) & 3u) == 0 && (job.dst_pitch & 3) == 0;
-    auto mload = [&](int yy, unsigned (&wv)[KD]) {
-        if (do_or && dst_al) {
-            const int yc = min(max(yy, 0), h - 1);
-            const uint8_t *rowd = job.dst + Xa + (size_t)yc * job.dst_pitch;  // uniform
-            gc_u32q p = (gc_u32q)(rowd + loff);
-#pragma unroll
-            for (int q = 0; q < KD; q++) wv[q] = p[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < KD; q++) wv[q] = 0;
-        }
-    };
 #pragma unroll
     for (int d = 0; d < PF; d++) {
         gload(Y0 + u + d, qe[d]);
         gload(Y0 - o + d, ql[d]);
         gload(Y0 + d, qc[d]);
-        mload(Y0 + d, qm[d]);
     }
 
     unsigned ones_a = 0, ones_b = 0;
@@ -218,19 +201,18 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
 
     for (int y = Y0; y < Y0 + rows; y++) {
         // ---- heads of the queues, then refill PF rows ahead ----
-        unsigned ev[KD], lv[KD], cv[KD], mv[KD];
+        unsigned ev[KD], lv[KD], cv[KD];
 #pragma unroll
-        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; mv[q] = qm[0][q]; }
+        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; }
 #pragma unroll
         for (int d = 0; d + 1 < PF; d++)
 #pragma unroll
             for (int q = 0; q < KD; q++) {
-                qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q]; qm[d][q] = qm[d + 1][q];
+                qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q];
             }
         gload(y + u + PF, qe[PF - 1]);
         gload(y - o + PF, ql[PF - 1]);
         gload(y + PF, qc[PF - 1]);
-        mload(y + PF, qm[PF - 1]);
         // entering row y+u and leaving row y-o together: with d = pe - pl and t = pe + pl per column,
         // S += d and Q += pe^2 - pl^2 = d * t (one signed 24-bit multiply-add); a row outside the image
         // contributes zeros (wave-uniform selects)
@@ -312,14 +294,14 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             const bool aligned = (reinterpret_cast<uintptr_t>(d) & 3u) == 0;
             if (all && aligned) {
 #pragma unroll
-                for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(d)[q] = outa[q] | mv[q];   // mv = 0 unless OR mode
+                for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(d)[q] = outa[q];
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) {
                     const int c = c0 + i;
                     if (c >= X0 && c < X0 + nout) {
                         uint8_t v = (uint8_t)((outa[i / 4] >> (8 * (i & 3))) & 0xffu);
-                        d[i] = do_or ? (uint8_t)(d[i] | v) : v;
+                        d[i] = v;
                     }
                 }
             }

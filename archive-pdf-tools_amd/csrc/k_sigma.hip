@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void sel_reset_kernel(const SigJob *jobs) {
 constexpr int DWT_RPB = 4;
 template <class T>
 __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> F, size_t dd_off) {
-    using U = typename Key<T>::U;
     const SigJob J = jobs[blockIdx.z];
     const int w = J.w, h = J.h, pitch = J.pitch;
     constexpr bool AS_BOOL = sizeof(T) == 8;               // the float64 path is PyWavelets' treatment of bool arrays

@@ -167,7 +167,6 @@ struct SauvolaJob {
 
 enum SauvolaFlags {
     SAUVOLA_INVERT = 1,   // store 1 for dark (mrc.threshold_image polarity)
-    SAUVOLA_OR = 2,       // dst |= result instead of dst = result
 };
 
 int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
