@@ -98,7 +98,7 @@ template <int K, bool MULTI>
 __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
     constexpr int KD = K / 4;
-    constexpr int PF = 4;                              // rows in flight
+    constexpr int PF = (K == 8) ? 2 : 4;               // rows in flight
     // Prefix rows in LDS, transposed: strip column ci = K*t + i lives at [i][t + PL].  A wave's
     // accesses for one pixel index i are then consecutive dwords (conflict-free); the natural
     // [ci] order would put lanes 16 B apart = a 4-way bank conflict on every read.  PL lanes of
