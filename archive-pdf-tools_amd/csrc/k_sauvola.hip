@@ -78,13 +78,13 @@ __device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) 
 // truncated integer quotients (pyx:144-145) -- mean*mean and the variance are exact, and the rest
 // is the reference's own operation sequence.  Cheaper than integer quotients + conversions:
 // 3 conversions instead of 4 and no correction steps.
-__device__ __forceinline__ bool sauvola_form_d(unsigned S, unsigned Q, unsigned px, double rc, double hrc, bool kpos,
-                                               double km1, double k2) {
-    const double mean = __builtin_floor(__builtin_fma((double)S, rc, hrc));
-    const double qd = __builtin_floor(__builtin_fma((double)Q, rc, hrc));
+__device__ __forceinline__ bool sauvola_form_dd(double Sd, double Qd, double pxd, double rc, double hrc, bool kpos,
+                                                double km1, double k2) {
+    const double mean = __builtin_floor(__builtin_fma(Sd, rc, hrc));
+    const double qd = __builtin_floor(__builtin_fma(Qd, rc, hrc));
     const double mm = __dmul_rn(mean, mean);
     const double variance = __dadd_rn(qd, -mm);
-    const double tmp = __dadd_rn((double)px, __dmul_rn(mean, km1));
+    const double tmp = __dadd_rn(pxd, __dmul_rn(mean, km1));
     const double lhs = __dmul_rn(tmp, tmp);
     const double rhs = __dmul_rn(__dmul_rn(mm, k2), variance);
     const bool neg = tmp <= 0;
@@ -275,15 +275,19 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 hrcd = 0.5 * rcd;
             }
             const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
-            const bool form = sauvola_form_d(S, Q, px, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
+            const double Sd = (double)S, Qd = (double)Q, pxd = (double)px;
+            const bool form = sauvola_form_dd(Sd, Qd, pxd, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
             const unsigned bit = valid ? ((form ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;   // pyx:153 (+ mrc.py:85)
             outa[i / 4] |= bit << (8 * (i & 3));
             ones_a += bit;
             if (job.dst_inv) {
                 // the same window on the image 255-p (mrc.py:224, 235)
-                const unsigned Si = __umul24(255u, count) - S;
-                const unsigned Qi = __umul24(65025u, count) - __umul24(510u, S) + Q;     // S < 2^24
-                const bool fi = sauvola_form_d(Si, Qi, 255u - px, rcd, hrcd, kpos, P.km1, P.k2);
+                // sum(255-p) = 255 n - S, sum((255-p)^2) = 65025 n - 510 S + Q: integers below 2^32, exact in
+                // fp64 whatever the rounding of the fmas (three conversions saved)
+                const double cd = (double)count;
+                const double Sid = __builtin_fma(255.0, cd, -Sd);
+                const double Qid = __builtin_fma(-510.0, Sd, __builtin_fma(65025.0, cd, Qd));
+                const bool fi = sauvola_form_dd(Sid, Qid, 255.0 - pxd, rcd, hrcd, kpos, P.km1, P.k2);
                 const unsigned bi = valid ? ((fi ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;
                 outb[i / 4] |= bi << (8 * (i & 3));
                 ones_b += bi;
