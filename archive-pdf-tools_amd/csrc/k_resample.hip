@@ -520,8 +520,9 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
     t.ntiles = cdiv(t.nout, 16);
     t.kbase.assign(t.ntiles, 0);
     t.bias.assign((size_t)t.ntiles * 16, 0);
-    // first input byte of a tile, aligned down as far as that does not cost another 64-byte block
-    // (16-byte aligned line loads are cheaper for the memory pipeline, a third MFMA block is not)
+    // first input byte of a tile, aligned down to 16 bytes when two 64-byte blocks still cover the tile
+    // (aligned bases allow the workgroup-wide panel loads; a third MFMA block is not worth it), else as
+    // far as it costs no extra block
     int KB = 1;
     for (int kalign = 16; kalign >= 1; kalign /= 4) {          // 16, 4, 1
         KB = 1;
@@ -550,7 +551,7 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
             if (hi >= 0) KB1 = std::max(KB1, cdiv(hi - lo + 1, 64));
         }
         t.kalign = kalign;
-        if (KB == KB1) break;
+        if (KB == KB1 || (kalign == 16 && KB <= 2)) break;     // a second block is cheaper than losing the panel loads
     }
     if (KB > 2) return false;
     t.KB = KB;
