@@ -161,3 +161,25 @@ def test_lanczos_ingest_downsample_matches_pillow_vectors_and_oracle():
         got = mrc.thumbnail(a, (w / ds, h / ds), resample='lanczos', reducing_gap=None)
         exp = O.thumbnail_ex(a, int(w / ds), int(h / ds), 'lanczos', None)
         assert got.shape == exp.shape and np.array_equal(got, exp), (shape, ds)
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_many_overlapping_boxes_later_box_wins_under_the_page_threshold(seed):
+    """mask[t:b, l:r] = th box after box (mrc.py:266), then mask |= page threshold (mrc.py:329).  The device
+    stores the page threshold first and ORs each pixel's LAST deciding box on top; random heavily overlapping
+    boxes (both polarities, some undecided) must give the same mask."""
+    rng = np.random.RandomState(seed)
+    w, h = 640, 420
+    img, _ = synth.synth_page(w, h, 3, seed=40 + seed, noise_sigma=5.0, line_div=14)
+    img[200:330, 60:600] = 255 - img[200:330, 60:600]            # a light-on-dark block: inverted-polarity decisions
+    lines = []
+    for _ in range(14):
+        l, t = int(rng.randint(0, w - 80)), int(rng.randint(0, h - 40))
+        r, b = min(w, l + int(rng.randint(40, 400))), min(h, t + int(rng.randint(12, 120)))
+        lines.append({'bbox': [l, t, r, b], 'words': [{'text': 'w', 'confidence': 80}]})
+    hocr = [{'lines': lines}]
+    got, exp = both(img, hocr, denoise_mask='fast', bg_downsample=3)
+    for a, b in zip(got, exp):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    got, exp = both(img, hocr, denoise_mask='none')
+    assert np.array_equal(got[0], exp[0])
