@@ -72,8 +72,9 @@ __device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) 
 
 // The reference's decision (pyx:143-153) for one pixel; returns `form`.  The whole of it runs in
 // fp64, divisions included.  floor(N / c) for integers N < 2^32, 1 <= c < 2^17:
-// (N + 0.5) / c is at least 0.5/c away from every integer while the fma below (N exact, rc = 1/c to
-// a few ulp, one rounding) is off by less than (N/c) * 2^-50 < 0.5/c, so the floor is exact.  mean
+// (N + 0.5) / c is at least 0.5/c away from every integer while the fma below (N exact, rc = 1/c
+// correctly rounded -- the hardware reciprocal alone is only a ~2^-26 seed and does flip near-ties --
+// one rounding) is off by less than (N/c) * 2^-51 < 0.5/c, so the floor is exact.  mean
 // and Q/count are then integer-valued doubles -- the very values the reference converts from its
 // truncated integer quotients (pyx:144-145) -- mean*mean and the variance are exact, and the rest
 // is the reference's own operation sequence.  Cheaper than integer quotients + conversions:
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
 
         // wave-uniform count / reciprocal when every output of the strip has the full window width
         const unsigned ucount = (unsigned)(P.ww * nrows);
-        const double urcd = __builtin_amdgcn_rcp((double)ucount), uhrcd = 0.5 * urcd;
+        const double urcd = 1.0 / (double)ucount, uhrcd = 0.5 * urcd;     // correctly rounded (v_rcp_f64 alone is a ~2^-26 seed)
 
         unsigned outa[KD], outb[KD];
 #pragma unroll
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             if (!full_cols) {
                 const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
                 count = (unsigned)max(ncols * nrows, 1);
-                rcd = __builtin_amdgcn_rcp((double)count);
+                rcd = 1.0 / (double)count;
                 hrcd = 0.5 * rcd;
             }
             const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored

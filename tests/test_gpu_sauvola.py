@@ -87,3 +87,17 @@ def test_config_sizes_digest_and_property():
     # but translating the page by a multiple of the tile leaves interior results unchanged
     sub = run_gpu(np.ascontiguousarray(img[1000:2000, 500:2500]), 51, 51, 0.34)
     assert np.array_equal(sub[26:-26, 26:-26], got[1026:1974, 526:2474])
+
+
+def test_near_tie_found_by_the_fuzzer():
+    """tools/fuzz_parity.py case: at pixel (31, 67) Q/count = 52231.9987 and the decision's two sides differ by
+    4e-4 relative, so a quotient off by one flips the pixel.  (The hardware fp64 reciprocal alone is a ~2^-26
+    seed and did exactly that; the kernel divides with a correctly rounded 1/count.)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sauvola_neartie.npz'))
+    img = np.ascontiguousarray(z['img'])
+    ww, wh, k, R = z['params']
+    h, w = img.shape
+    out = np.empty(h * w, np.uint8)
+    sauvola.binarise_sauvola(img.reshape(-1), out, w, h, int(ww), int(wh), float(k), float(R))
+    assert np.array_equal(out.reshape(h, w), z['expected'])

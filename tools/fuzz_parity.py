@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (kernel entry points and whole-page decompositions over random
+shapes / windows / k / n_size / downsample factors / hOCR boxes).  Not part of the pytest suite (minutes);
+run on a GPU box:  python tools/fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import numpy as np
+import mrc_oracle as O
+from mrchip import _lib, mrc, sauvola, optimiser, synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.RandomState(seed)
+lib, ctx = _lib.load(), _lib.default_context()
+t0 = time.time()
+counts = {}
+
+
+def tick(name):
+    counts[name] = counts.get(name, 0) + 1
+
+
+def rnd_img(h, w, c=1):
+    kind = rng.randint(4)
+    if kind == 0:
+        a = rng.randint(0, 256, (h, w) if c == 1 else (h, w, c))
+    elif kind == 1:
+        a = np.full((h, w) if c == 1 else (h, w, c), rng.randint(0, 256))
+        a = a + rng.randint(-3, 4, a.shape)
+    else:
+        img, _ = synth.synth_page(max(w, 64), max(h, 64), c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 2, 6, 14])),
+                                  line_div=int(rng.choice([8, 14, 30])))
+        a = img[:h, :w]
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+while time.time() - t0 < budget:
+    what = rng.randint(6)
+    if what == 0:       # sauvola
+        h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
+        ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
+        if rng.rand() < 0.5: wh = ww
+        k = float(rng.choice([0.34, 0.1, 0.5, -0.2, 0.0, 1.0])); R = float(rng.choice([128.0, 64.0, 200.0]))
+        g = rnd_img(h, w)
+        out = np.empty(h * w, np.uint8)
+        sauvola.binarise_sauvola(g.reshape(-1), out, w, h, ww, wh, k, R)
+        exp = np.empty(h * w, np.uint8)
+        O.binarise_sauvola(g.reshape(-1), exp, w, h, ww, wh, k, R)
+        if not np.array_equal(out, exp):
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'fuzz_fail.npz'), g=g, out=out, exp=exp, params=np.array([h, w, ww, wh, k, R]))
+            bad = np.argwhere(out.reshape(h, w) != exp.reshape(h, w))
+            print('MISMATCH sauvola', (h, w, ww, wh, k, R), len(bad), bad[:10].tolist())
+            raise SystemExit(1)
+        tick('sauvola')
+    elif what == 1:     # optimise
+        h, w = int(rng.randint(1, 400)), int(rng.randint(1, 1300))
+        c = int(rng.choice([1, 3])); n = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 20]))
+        img = rnd_img(h, w, c)
+        mask = (rng.rand(h, w) < rng.choice([0.02, 0.1, 0.5, 0.9, 1.0, 0.0])).astype(np.uint8)
+        f = optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2
+        got = f(mask, img, w, h, n)
+        exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+        assert np.array_equal(got, exp), ('optimise', h, w, c, n)
+        tick('optimise')
+    elif what == 2:     # denoise
+        h, w = int(rng.randint(1, 500)), int(rng.randint(1, 1400))
+        mask = (rng.rand(h, w) < rng.choice([0.01, 0.05, 0.2, 0.5])).astype(np.uint8)
+        got = mask.copy(); optimiser.fast_mask_denoise(got, w, h, 4, 2)
+        exp = O.fast_mask_denoise(mask.copy(), w, h, 4, 2)
+        assert np.array_equal(got, exp), ('denoise', h, w)
+        tick('denoise')
+    elif what == 3:     # thumbnails
+        h, w = int(rng.randint(8, 900)), int(rng.randint(8, 1400)); c = int(rng.choice([1, 3]))
+        img = rnd_img(h, w, c)
+        ds = float(rng.choice([1.3, 2, 2.5, 3, 3.7, 4, 5, 6.5, 9]))
+        flt = str(rng.choice(['bicubic', 'lanczos'])); gap = None if rng.rand() < 0.5 else 2.0
+        rw, rh = int(w / ds), int(h / ds)
+        if rw < 1 or rh < 1: continue
+        got = mrc.thumbnail(img, (w / ds, h / ds), resample=flt, reducing_gap=gap)
+        exp = O.thumbnail_ex(img, rw, rh, flt, gap)
+        assert got.shape == exp.shape and np.array_equal(got, exp), ('thumbnail', h, w, c, ds, flt, gap)
+        tick('thumbnail')
+    elif what == 4:     # gaussian
+        h, w = int(rng.randint(2, 500)), int(rng.randint(2, 1300))
+        g = rnd_img(h, w)
+        sig = float(rng.choice([0.15, 0.3, 0.45, 0.63, 0.9, 1.3, 2.1, 3.3]))
+        wts, radius = mrc.gaussian_weights(sig)
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
+        exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
+        assert np.array_equal(out, exp), ('gauss', h, w, sig)
+        tick('gauss')
+    else:               # whole pages
+        h, w = int(rng.randint(20, 900)), int(rng.randint(20, 1300)); c = int(rng.choice([1, 3]))
+        img, hocr = synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 6, 12, 25])),
+                                     line_div=int(rng.choice([6, 10, 20, 40])))
+        kw = dict(dpi=rng.choice([None, 100, 200, 364, 400]), bg_downsample=rng.choice([None, 2, 3, 4]),
+                  fg_downsample=rng.choice([None, 2, 3]), denoise_mask=str(rng.choice(['fast', 'none'])))
+        kw = {k: (None if v is None else (v if isinstance(v, str) else int(v))) for k, v in kw.items()}
+        g = mrc.create_mrc_hocr_components(img, hocr, **kw)
+        e = O.create_mrc_hocr_components(img, hocr, **kw)
+        for i in range(3):
+            a, b = next(g), next(e)
+            assert a.shape == b.shape and np.array_equal(a, b), ('page', h, w, c, kw, i)
+        tick('page')
+print('fuzz ok: %.0f s, seed %d, cases %s' % (time.time() - t0, seed, counts))
