@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * PNW) void resize_mm_panel_kernel(const uint8_t
                                                                    uint8_t *dst, int dpitch, size_t dstride, int nout, int ntiles,
                                                                    const int32_t *kbase, const int32_t *bias, const v4i *btab,
                                                                    int quads_per_wave, int pad_ok, int gx, int gy, int gz,
-                                                                   int panel_w, int pws) {
+                                                                   int panel_w, int pws, int line_bytes) {
     const int total = gx * gy * gz, per = (total + 7) >> 3;            // XCD-contiguous work order (see above)
     const int V = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (V >= total || (int)(blockIdx.x >> 3) >= per) return;
@@ -455,7 +455,10 @@ __global__ __launch_bounds__(64 * PNW) void resize_mm_panel_kernel(const uint8_t
     unsigned char *op = outP + wv * 16 * OSTR;
     const int cpl = panel_w >> 4;                                     // 16-byte chunks per line
     const int ld_line = tid / cpl, ld_chunk = tid - ld_line * cpl;
-    const bool loader = tid < 16 * cpl;
+    // chunks that start past the end of a line hold no tap (their coefficients are zero) and are not loaded:
+    // the panel is as wide as the widest workgroup needs, the last workgroups of a line would otherwise read
+    // up to panel_w bytes past the line -- past the allocation for the last line of a small buffer
+    const bool loader = tid < 16 * cpl && kbP + ld_chunk * 16 < line_bytes;
 
     auto gload = [&](int g) -> v4i {
         const int line = min(g * 16 + ld_line, nlines - 1);           // past the end: repeat the last line (never stored)
@@ -710,7 +713,8 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
     LAUNCH(ctx, s, nm, a,                                                                                                 \
            hipLaunchKernelGGL((resize_mm_panel_kernel<KBB>), grid, dim3(64 * PNW), lds, s, in.p, in.pitch, in.stride, nlines, \
                               out.p, out.pitch, out.stride, M.nout, M.ntiles, tptr(p.off_mm[pass][0]),                     \
-                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages, M.panel_w, pws))
+                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages, M.panel_w, pws,     \
+                              pass == 0 ? cw * c : ch_))
                 if (M.KB == 1) MMP_LAUNCH(1); else MMP_LAUNCH(2);
 #undef MMP_LAUNCH
                 continue;

@@ -161,6 +161,13 @@ def test_lanczos_ingest_downsample_matches_pillow_vectors_and_oracle():
         got = mrc.thumbnail(a, (w / ds, h / ds), resample='lanczos', reducing_gap=None)
         exp = O.thumbnail_ex(a, int(w / ds), int(h / ds), 'lanczos', None)
         assert got.shape == exp.shape and np.array_equal(got, exp), (shape, ds)
+    # fuzzer case: Image.reduce(2) then Lanczos on a 231-pixel-wide intermediate -- the line panel of the last
+    # workgroup used to be loaded past the end of the (small) scratch image
+    for _ in range(20):
+        a = rng.randint(0, 256, (695, 461, 3)).astype(np.uint8)
+        got = mrc.thumbnail(a, (461 / 5.0, 695 / 5.0), resample='lanczos', reducing_gap=2.0)
+        exp = O.thumbnail_ex(a, 92, 139, 'lanczos', 2.0)
+        assert np.array_equal(got, exp)
 
 
 @pytest.mark.parametrize('seed', [1, 2, 3])

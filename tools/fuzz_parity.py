@@ -36,6 +36,15 @@ def rnd_img(h, w, c=1):
     return np.clip(a, 0, 255).astype(np.uint8)
 
 
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+_last = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_last_%d.txt' % seed), 'w')
+
+
+def note(*a):
+    """the case about to run, flushed: a GPU fault kills the process, this line says which case it was"""
+    _last.seek(0); _last.truncate(); _last.write(repr(a) + '\n'); _last.flush(); os.fsync(_last.fileno())
+
+
 while time.time() - t0 < budget:
     what = rng.randint(6)
     if what == 0:       # sauvola
@@ -44,6 +53,7 @@ while time.time() - t0 < budget:
         if rng.rand() < 0.5: wh = ww
         k = float(rng.choice([0.34, 0.1, 0.5, -0.2, 0.0, 1.0])); R = float(rng.choice([128.0, 64.0, 200.0]))
         g = rnd_img(h, w)
+        note('sauvola', h, w, ww, wh, k, R)
         out = np.empty(h * w, np.uint8)
         sauvola.binarise_sauvola(g.reshape(-1), out, w, h, ww, wh, k, R)
         exp = np.empty(h * w, np.uint8)
@@ -60,6 +70,7 @@ while time.time() - t0 < budget:
         c = int(rng.choice([1, 3])); n = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 20]))
         img = rnd_img(h, w, c)
         mask = (rng.rand(h, w) < rng.choice([0.02, 0.1, 0.5, 0.9, 1.0, 0.0])).astype(np.uint8)
+        note('optimise', h, w, c, n, float(mask.mean()))
         f = optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2
         got = f(mask, img, w, h, n)
         exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
@@ -68,6 +79,7 @@ while time.time() - t0 < budget:
     elif what == 2:     # denoise
         h, w = int(rng.randint(1, 500)), int(rng.randint(1, 1400))
         mask = (rng.rand(h, w) < rng.choice([0.01, 0.05, 0.2, 0.5])).astype(np.uint8)
+        note('denoise', h, w)
         got = mask.copy(); optimiser.fast_mask_denoise(got, w, h, 4, 2)
         exp = O.fast_mask_denoise(mask.copy(), w, h, 4, 2)
         assert np.array_equal(got, exp), ('denoise', h, w)
@@ -79,6 +91,7 @@ while time.time() - t0 < budget:
         flt = str(rng.choice(['bicubic', 'lanczos'])); gap = None if rng.rand() < 0.5 else 2.0
         rw, rh = int(w / ds), int(h / ds)
         if rw < 1 or rh < 1: continue
+        note('thumbnail', h, w, c, ds, flt, gap)
         got = mrc.thumbnail(img, (w / ds, h / ds), resample=flt, reducing_gap=gap)
         exp = O.thumbnail_ex(img, rw, rh, flt, gap)
         assert got.shape == exp.shape and np.array_equal(got, exp), ('thumbnail', h, w, c, ds, flt, gap)
@@ -88,6 +101,7 @@ while time.time() - t0 < budget:
         g = rnd_img(h, w)
         sig = float(rng.choice([0.15, 0.3, 0.45, 0.63, 0.9, 1.3, 2.1, 3.3]))
         wts, radius = mrc.gaussian_weights(sig)
+        note('gauss', h, w, sig)
         out = np.empty_like(g)
         _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
         exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
@@ -100,6 +114,7 @@ while time.time() - t0 < budget:
         kw = dict(dpi=rng.choice([None, 100, 200, 364, 400]), bg_downsample=rng.choice([None, 2, 3, 4]),
                   fg_downsample=rng.choice([None, 2, 3]), denoise_mask=str(rng.choice(['fast', 'none'])))
         kw = {k: (None if v is None else (v if isinstance(v, str) else int(v))) for k, v in kw.items()}
+        note('page', h, w, c, kw)
         g = mrc.create_mrc_hocr_components(img, hocr, **kw)
         e = O.create_mrc_hocr_components(img, hocr, **kw)
         for i in range(3):
