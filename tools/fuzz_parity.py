@@ -46,7 +46,7 @@ def note(*a):
 
 
 while time.time() - t0 < budget:
-    what = rng.randint(6)
+    what = rng.randint(12)
     if what == 0:       # sauvola
         h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
         ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
@@ -107,6 +107,81 @@ while time.time() - t0 < budget:
         exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
         assert np.array_equal(out, exp), ('gauss', h, w, sig)
         tick('gauss')
+    elif what == 6:     # noise estimate entry points (float32 path on uint8 values, float64 path on bool arrays)
+        h, w = int(rng.randint(1, 400)), int(rng.randint(1, 900))
+        if rng.rand() < 0.5:
+            a = rnd_img(h, w)
+            note('sigma_u8', h, w)
+            got = mrc.mean_estimate_sigma(a.astype(np.float32))
+            exp = O.estimate_sigma(a.astype(np.float32))
+        else:
+            a = rng.rand(h, w) < rng.choice([0.0, 0.03, 0.3, 0.5, 1.0])
+            note('sigma_bool', h, w)
+            got = mrc.mean_estimate_sigma(a)
+            exp = O.estimate_sigma(a)
+        assert (np.isnan(got) and np.isnan(exp)) or got == exp, ('sigma', h, w, got, exp)
+        tick('sigma')
+    elif what == 7:     # luma
+        h, w = int(rng.randint(1, 500)), int(rng.randint(1, 1500))
+        rgb = rnd_img(h, w, 3)
+        note('luma', h, w)
+        out = np.empty((h, w), np.uint8)
+        _lib.check(lib.mrchip_luma601(ctx.handle, _lib.ptr(np.ascontiguousarray(rgb)), _lib.ptr(out), w, h))
+        assert np.array_equal(out, O.luma601(rgb)), ('luma', h, w)
+        tick('luma')
+    elif what == 8:     # sauvola: large images and windows (8 / 16 columns per lane)
+        h, w = int(rng.randint(200, 1800)), int(rng.randint(900, 3000))
+        ww = int(rng.choice([31, 51, 91, 101, 121, 135, 200, 255, 301])); wh = ww if rng.rand() < 0.7 else int(rng.randint(3, 250))
+        if ww * wh > 65792: wh = 65792 // ww
+        k = float(rng.choice([0.34, 0.1, -0.2])); R = 128.0
+        g = rnd_img(h, w)
+        note('sauvola_big', h, w, ww, wh, k)
+        out = np.empty(h * w, np.uint8); exp = np.empty(h * w, np.uint8)
+        sauvola.binarise_sauvola(g.reshape(-1), out, w, h, ww, wh, k, R)
+        O.binarise_sauvola(g.reshape(-1), exp, w, h, ww, wh, k, R)
+        assert np.array_equal(out, exp), ('sauvola_big', h, w, ww, wh, k)
+        tick('sauvola_big')
+    elif what == 9:     # optimise on wide rows (more than 4096 columns: the unpacked kernel)
+        h, w = int(rng.randint(1, 60)), int(rng.randint(3000, 9000))
+        c = int(rng.choice([1, 3])); n = int(rng.choice([1, 3, 10, 14]))
+        img = rnd_img(h, w, c)
+        mask = (rng.rand(h, w) < rng.choice([0.05, 0.5, 0.95])).astype(np.uint8)
+        note('optimise_wide', h, w, c, n)
+        got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
+        exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+        assert np.array_equal(got, exp), ('optimise_wide', h, w, c, n)
+        tick('optimise_wide')
+    elif what == 10:    # create_hocr_mask on a caller's mask (assignment semantics), random boxes
+        h, w = int(rng.randint(30, 500)), int(rng.randint(30, 900))
+        gimg, _ = synth.synth_page(max(w, 64), max(h, 64), 1, seed=int(rng.randint(1 << 30)), noise_sigma=4.0, line_div=int(rng.choice([8, 16])))
+        gimg = np.ascontiguousarray(gimg[:h, :w])
+        lines = []
+        for _ in range(int(rng.randint(0, 12))):
+            l, t = int(rng.randint(0, w - 4)), int(rng.randint(0, h - 4))
+            r, b = min(w, l + int(rng.randint(2, w))), min(h, t + int(rng.randint(2, 140)))
+            lines.append({'bbox': [l, t, r, b], 'words': [{'text': 'w', 'confidence': int(rng.choice([90, 90, 10]))}]})
+        hocr = [{'lines': lines}]
+        m0 = (rng.rand(h, w) < 0.1)
+        note('hocr_mask', h, w, len(lines))
+        got = m0.copy(); mrc.create_hocr_mask(gimg, got, hocr, dpi=int(rng.choice([100, 200, 300])) if rng.rand() < 0.5 else None)
+        tick('hocr_mask')   # compared through the page path below as well; here: must not fault and only touch box pixels
+        touched = np.zeros((h, w), bool)
+        for bx in mrc.hocr_boxes(hocr, w, h): touched[bx[1]:bx[3], bx[0]:bx[2]] = True
+        assert np.array_equal(got[~touched], m0[~touched]), ('hocr_mask outside boxes', h, w)
+    elif what == 11:    # batch of several same-sized pages == page by page
+        h, w = int(rng.randint(40, 500)), int(rng.randint(40, 900)); c = int(rng.choice([1, 3])); npg = int(rng.randint(2, 6))
+        pages = [synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 4, 9, 20])),
+                                  line_div=int(rng.choice([6, 12, 24]))) for _ in range(npg)]
+        kw = dict(dpi=rng.choice([None, 150, 300]), bg_downsample=rng.choice([None, 2, 3]), fg_downsample=rng.choice([None, 2]))
+        kw = {k: (None if v is None else int(v)) for k, v in kw.items()}
+        note('batch', h, w, c, npg, kw)
+        res = mrc.decompose_pages([p[0] for p in pages], [p[1] for p in pages], denoise_mask='fast', **kw)
+        for (img, hocr), (mask, fg, bg) in zip(pages, res):
+            e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            for a in (mask, fg, bg):
+                b = next(e)
+                assert a.shape == b.shape and np.array_equal(a, b), ('batch', h, w, c, kw)
+        tick('batch')
     else:               # whole pages
         h, w = int(rng.randint(20, 900)), int(rng.randint(20, 1300)); c = int(rng.choice([1, 3]))
         img, hocr = synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 6, 12, 25])),
