@@ -634,6 +634,260 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     }
 }
 
+// Rows of 4097..8160 columns: the same packed scheme with TWO groups of 4 columns per thread (columns
+// 4t.. and 4(t+T)..), so that 1024 threads still cover the row and the LDS rows (one entry per column) stay
+// within 160 KiB.  The per-group state doubles, so the next row's loads are not held in registers a row
+// ahead (the 128-VGPR budget of a 1024-thread workgroup): each row loads what it needs for both groups up
+// front.  Same arithmetic, same LDS layout (entry index = column + column/4), two barriers per row.
+template <int C, int NH, int NCT>
+__device__ __forceinline__ void optimise_packed_wide_rows(const OptJob &J, unsigned char *smem) {
+    constexpr int P = 4, G = 2;
+    constexpr int EW = (C == 3) ? 2 : 1;
+    constexpr int ND = P * C / 4;
+    const uint8_t *__restrict__ mask = J.mask;
+    const uint8_t *__restrict__ img = J.img;
+    uint8_t *out = J.out;
+    const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h;
+    const int n = NCT >= 0 ? NCT : J.n;
+    const unsigned invm = J.invert ? 0xffffffffu : 0u;
+    const int npad = n;
+    const int T = blockDim.x, t = threadIdx.x;
+    const int wr = min(G * T * P, (w + 3) & ~3);
+    const int nent = wr + 2 * npad;
+    const int nelem = nent + nent / P + 1;
+    unsigned *firA = reinterpret_cast<unsigned *>(smem);
+    unsigned *iirA = firA + (size_t)nelem * EW;
+    for (int i = t; i < 2 * nelem * EW; i += T) firA[i] = 0;
+    __syncthreads();
+    struct Ent { unsigned d[EW]; };
+    auto eadd = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] += b.d[k];
+    };
+    auto esub = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] -= b.d[k];
+    };
+    // column -> dword index of its entry (one pad entry per 4 columns)
+    auto eidx = [&](int col) { const int d = col + npad; return (d + (d >> 2)) * EW; };
+    auto lds_ld = [&](const unsigned *A, int col) {
+        Ent e;
+        const unsigned *p = A + eidx(col);
+        if constexpr (EW == 2) { uint2 v = *reinterpret_cast<const uint2 *>(p); e.d[0] = v.x; e.d[1] = v.y; }
+        else e.d[0] = p[0];
+        return e;
+    };
+    int x0[G];
+    unsigned colm[G], pxm[G][ND];
+    Ent firE[G][P], iirE[G][P];
+    unsigned prev[G][ND];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        x0[g] = (t + g * T) * P;
+        colm[g] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (x0[g] + b < w) colm[g] |= 0xffu << (8 * b);
+#pragma unroll
+        for (int q = 0; q < ND; q++) {
+            unsigned m = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (x0[g] + (4 * q + b) / C < w) m |= 0xffu << (8 * b);
+            pxm[g][q] = m;
+            prev[g][q] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+#pragma unroll
+            for (int k = 0; k < EW; k++) { firE[g][i].d[k] = 0; iirE[g][i].d[k] = 0; }
+    }
+    auto on_bytes = [&](unsigned m, unsigned cm) {
+        unsigned tt = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;
+        tt = (tt - (tt >> 7)) | tt;
+        return (tt ^ invm) & cm;
+    };
+    auto fir_entries = [&](const RowRegs<C, P> &r, unsigned cm, Ent (&e)[P]) {
+        const unsigned on = on_bytes(r.m[0], cm);
+        const unsigned on01 = on & 0x01010101u;
+        if constexpr (C == 3) {
+            const unsigned d0 = r.px[0] & __builtin_amdgcn_perm(0u, on, 0x01000000u);
+            const unsigned d1 = r.px[1] & __builtin_amdgcn_perm(0u, on, 0x02020101u);
+            const unsigned d2 = r.px[2] & __builtin_amdgcn_perm(0u, on, 0x03030302u);
+            e[0].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(on01, d0, 0x0c040c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(on01, d1, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(d2, d1, 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c060c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(d2, d2, 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c070c03u);
+        } else {
+            const unsigned d0 = r.px[0] & on;
+            e[0].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c040c00u);
+            e[1].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c060c02u);
+            e[3].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c070c03u);
+        }
+    };
+    auto iir_entries = [&](const unsigned (&o)[ND], Ent (&e)[P]) {
+        if constexpr (C == 3) {
+            e[0].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(0u, o[0], 0x0c0c0c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(0u, o[1], 0x0c0c0c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(o[2], o[1], 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(o[2], o[2], 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c03u);
+        } else {
+            e[0].d[0] = o[0] & 0xffu; e[1].d[0] = (o[0] >> 8) & 0xffu; e[2].d[0] = (o[0] >> 16) & 0xffu; e[3].d[0] = o[0] >> 24;
+        }
+    };
+    auto fir_apply = [&](int g, const RowRegs<C, P> &r, bool plus) {
+        Ent e[P];
+        fir_entries(r, colm[g], e);
+#pragma unroll
+        for (int i = 0; i < P; i++) { if (plus) eadd(firE[g][i], e[i]); else esub(firE[g][i], e[i]); }
+    };
+    // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
+    for (int yy = 0; yy < min(h, n - 1); yy++)
+#pragma unroll
+        for (int g = 0; g < G; g++) fir_apply(g, load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0[g]), true);
+
+    for (int y = 0; y < h; y++) {
+        RowRegs<C, P> r_cur[G];
+        // ---- this row's loads for both groups, then the vertical running sums ----
+        {
+            RowRegs<C, P> r_enter[G], r_leave[G];
+            unsigned o_leave[G][ND];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                r_enter[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y + n - 1, h, x0[g]);
+                r_leave[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y - n - 1, h, x0[g]);
+                r_cur[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y, h, x0[g]);
+                gc_u32p p = (gc_u32p)(out + (size_t)min(max(y - n - 1, 0), h - 1) * opitch + (size_t)x0[g] * C);
+#pragma unroll
+                for (int q = 0; q < ND; q++) o_leave[g][q] = p[q];
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (y + n - 1 < h && n >= 1) fir_apply(g, r_enter[g], true);       // ye = min(h, y+n)
+                if (y - n - 1 >= 0 && n >= 1) fir_apply(g, r_leave[g], false);     // ys = max(0, y-n)
+                if (y >= 1 && n >= 1) {
+                    Ent e[P];
+                    iir_entries(prev[g], e);
+#pragma unroll
+                    for (int i = 0; i < P; i++) eadd(iirE[g][i], e[i]);
+                }
+                if (y - n - 1 >= 0 && n >= 1) {
+                    unsigned ol[ND];
+#pragma unroll
+                    for (int q = 0; q < ND; q++) ol[q] = o_leave[g][q] & pxm[g][q];
+                    Ent e[P];
+                    iir_entries(ol, e);
+#pragma unroll
+                    for (int i = 0; i < P; i++) esub(iirE[g][i], e[i]);
+                }
+                if (x0[g] < wr)
+#pragma unroll
+                    for (int i = 0; i < P; i++) {
+                        const int e = eidx(x0[g] + i);
+                        if constexpr (EW == 2) {
+                            *reinterpret_cast<uint2 *>(firA + e) = make_uint2(firE[g][i].d[0], firE[g][i].d[1]);
+                            *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(iirE[g][i].d[0], iirE[g][i].d[1]);
+                        } else {
+                            firA[e] = firE[g][i].d[0];
+                            iirA[e] = iirE[g][i].d[0];
+                        }
+                    }
+            }
+        }
+        const int ys = max(0, y - n);
+        lds_barrier();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int xg = x0[g];
+            const unsigned on_cur = on_bytes(r_cur[g].m[0], colm[g]);
+            unsigned qd[ND];
+#pragma unroll
+            for (int q = 0; q < ND; q++) qd[q] = 0;
+            if (__any(on_cur != colm[g])) {          // some pixel of this wave's 256 columns wants a quotient
+                Ent aL, aR, aI;
+#pragma unroll
+                for (int k = 0; k < EW; k++) { aL.d[k] = 0; aR.d[k] = 0; aI.d[k] = 0; }
+                for (int j = -n; j < 0; j++) { eadd(aL, lds_ld(firA, xg + j)); eadd(aI, lds_ld(iirA, xg + j)); }
+                for (int j = 0; j < n; j++) {
+                    if constexpr (NH == 2) eadd(aR, lds_ld(firA, xg + j)); else eadd(aL, lds_ld(firA, xg + j));
+                }
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    const int x = xg + i;
+                    const int xs = max(0, x - n);
+                    int fsum[C], fcnt;
+                    if constexpr (C == 3) {
+                        fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)(aI.d[0] & 0xffffu);
+                        fsum[1] = (int)(aL.d[0] >> 16) + (int)(aI.d[0] >> 16);
+                        fsum[2] = (int)(aL.d[1] & 0xffffu) + (int)(aI.d[1] & 0xffffu);
+                        fcnt = (int)(aL.d[1] >> 16);
+                        if constexpr (NH == 2) {
+                            fsum[0] += (int)(aR.d[0] & 0xffffu); fsum[1] += (int)(aR.d[0] >> 16);
+                            fsum[2] += (int)(aR.d[1] & 0xffffu); fcnt += (int)(aR.d[1] >> 16);
+                        }
+                    } else {
+                        fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)aI.d[0];
+                        fcnt = (int)(aL.d[0] >> 16);
+                        if constexpr (NH == 2) { fsum[0] += (int)(aR.d[0] & 0xffffu); fcnt += (int)(aR.d[0] >> 16); }
+                    }
+                    const int cnt = fcnt + (y - ys) * (x - xs);
+                    const float rc = __builtin_amdgcn_rcpf((float)max(cnt, 1));   // 1 ulp: inside div_small's margin
+                    const float hrc = 0.5f * rc;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const unsigned q = (unsigned)__builtin_fmaf((float)fsum[c], rc, hrc);
+                        const int jb = i * C + c;
+                        qd[jb >> 2] |= q << (8 * (jb & 3));
+                    }
+                    if (i + 1 < P) {      // slide to pixel x+1
+                        if constexpr (NH == 2) {
+                            eadd(aL, firE[g][i]); esub(aL, lds_ld(firA, x - n));
+                            eadd(aR, lds_ld(firA, x + n)); esub(aR, firE[g][i]);
+                        } else {
+                            eadd(aL, lds_ld(firA, x + n)); esub(aL, lds_ld(firA, x - n));
+                        }
+                        eadd(aI, iirE[g][i]); esub(aI, lds_ld(iirA, x - n));
+                    }
+                }
+            }
+            // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient
+            unsigned res[ND];
+            if constexpr (C == 3) {
+                const unsigned e0 = __builtin_amdgcn_perm(0u, on_cur, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on_cur, 0x02020101u),
+                               e2 = __builtin_amdgcn_perm(0u, on_cur, 0x03030302u);
+                res[0] = ((r_cur[g].px[0] & e0) | (qd[0] & ~e0)) & pxm[g][0];
+                res[1] = ((r_cur[g].px[1] & e1) | (qd[1] & ~e1)) & pxm[g][1];
+                res[2] = ((r_cur[g].px[2] & e2) | (qd[2] & ~e2)) & pxm[g][2];
+            } else {
+                res[0] = ((r_cur[g].px[0] & on_cur) | (qd[0] & ~on_cur)) & pxm[g][0];
+            }
+            if (xg < w) {
+                uint8_t *o = out + (size_t)y * opitch + (size_t)xg * C;
+                if (xg + P <= w) {
+#pragma unroll
+                    for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+                } else {
+                    const int nbytes = (w - xg) * C;
+#pragma unroll
+                    for (int j = 0; j < P * C; j++)
+                        if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < ND; q++) prev[g][q] = res[q];
+        }
+        lds_barrier();         // everyone is done reading the LDS rows
+    }
+}
+
+template <int C, int NH>
+__global__ __launch_bounds__(1024) void optimise_packed_wide_kernel(const OptJob *jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const OptJob J = jobs[blockIdx.x];
+    if (J.n == 3) optimise_packed_wide_rows<C, 1, 3>(J, smem);
+    else if (J.n == 10 && NH == 2) optimise_packed_wide_rows<C, 2, 10>(J, smem);
+    else optimise_packed_wide_rows<C, NH, -1>(J, smem);
+}
+
 template <int C, int NH, int MAXT, bool DB>
 __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -701,6 +955,11 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
     } while (0)
 #define OPT_PACKED(CC, NHH, MT, NAME)                                                                    \
     do { if (db) OPT_PACKED2(CC, NHH, MT, true, NAME); else OPT_PACKED2(CC, NHH, MT, false, NAME); } while (0)
+    // wide rows: two groups of 4 columns per thread, LDS rows of one entry per column must still fit
+    const int wwr = std::min(g.T * 8, (w + 3) & ~3), wnent = wwr + 2 * n_max;
+    const size_t wlds = (size_t)(wnent + wnent / 4 + 1) * ((c == 3) ? 16 : 8);
+    static const bool no_wide = getenv("MRCHIP_OPT_NO_WIDE") != nullptr;
+    const bool wide_ok = !no_wide && wlds <= 160 * 1024;
     if (g.P == 4 && n_max <= 11) {
         // 16-bit lane capacity: one FIR accumulator up to n=8, two halves up to n=11
         if (c == 3) {
@@ -710,6 +969,18 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
             if (n_max <= 8) { if (g.T <= 512) OPT_PACKED(1, 1, 512, "optimise_gray"); else OPT_PACKED(1, 1, 1024, "optimise_gray"); }
             else { if (g.T <= 512) OPT_PACKED(1, 2, 512, "optimise_gray"); else OPT_PACKED(1, 2, 1024, "optimise_gray"); }
         }
+    } else if (g.P == 8 && n_max <= 11 && wide_ok) {
+        // 4097..8160 columns: two column groups per thread in the packed scheme
+#define OPT_WIDE(CC, NHH, NAME)                                                                          \
+    do {                                                                                                \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_packed_wide_kernel<CC, NHH>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));            \
+        LAUNCH(ctx, s, NAME, alg,                                                                       \
+               hipLaunchKernelGGL((optimise_packed_wide_kernel<CC, NHH>), dim3(njobs), dim3(g.T), wlds, s, d_jobs)); \
+    } while (0)
+        if (c == 3) { if (n_max <= 8) OPT_WIDE(3, 1, "optimise_rgb"); else OPT_WIDE(3, 2, "optimise_rgb"); }
+        else { if (n_max <= 8) OPT_WIDE(1, 1, "optimise_gray"); else OPT_WIDE(1, 2, "optimise_gray"); }
+#undef OPT_WIDE
     } else if (c == 3) OPT_PICK(3, "optimise_rgb");
     else OPT_PICK(1, "optimise_gray");
 #undef OPT_PACKED

@@ -190,3 +190,16 @@ def test_many_overlapping_boxes_later_box_wins_under_the_page_threshold(seed):
         assert a.shape == b.shape and np.array_equal(a, b)
     got, exp = both(img, hocr, denoise_mask='none')
     assert np.array_equal(got[0], exp[0])
+
+
+@pytest.mark.parametrize('w,c,n', [(4097, 3, 3), (5000, 3, 10), (8000, 3, 10), (8160, 1, 3), (8163, 3, 10), (8200, 1, 10), (6001, 3, 11), (5003, 3, 14)])
+def test_optimise_rows_wider_than_4096_columns(w, c, n):
+    """4097..8160 columns take the packed kernel with two column groups per thread; beyond that (or n > 11) the
+    unpacked one.  Both polarities of the mask, ragged right edges."""
+    rng = np.random.RandomState(w + n)
+    h = 37
+    img = rng.randint(0, 256, (h, w) if c == 1 else (h, w, 3)).astype(np.uint8)
+    for density in (0.08, 0.92):
+        mask = (rng.rand(h, w) < density).astype(np.uint8)
+        f, e = (optimiser.optimise_gray2, O.optimise_gray2) if c == 1 else (optimiser.optimise_rgb2, O.optimise_rgb2)
+        assert np.array_equal(f(mask, img, w, h, n), e(mask, img, w, h, n)), (w, c, n, density)
