@@ -72,13 +72,20 @@ __device__ __forceinline__ void load_px(const uint8_t *p, unsigned (&w)[K / 4]) 
 
 // The reference's decision (pyx:143-153) for one pixel; returns `form`.  The whole of it runs in
 // fp64, divisions included.  floor(N / c) for integers N < 2^32, 1 <= c < 2^17:
-// (N + 0.5) / c is at least 0.5/c away from every integer while the fma below (N exact, rc = 1/c
-// correctly rounded -- the hardware reciprocal alone is only a ~2^-26 seed and does flip near-ties --
-// one rounding) is off by less than (N/c) * 2^-51 < 0.5/c, so the floor is exact.  mean
+// (N + 0.5) / c is at least 0.5/c away from every integer while the fma below (N exact, rc = 1/c to
+// ~2^-51, see rcp_nr, one rounding) is off by less than (N/c) * 2^-50 < 0.5/c, so the floor is exact.  mean
 // and Q/count are then integer-valued doubles -- the very values the reference converts from its
 // truncated integer quotients (pyx:144-145) -- mean*mean and the variance are exact, and the rest
 // is the reference's own operation sequence.  Cheaper than integer quotients + conversions:
 // 3 conversions instead of 4 and no correction steps.
+// 1/c for the quotients below: the hardware reciprocal is a ~2^-26 seed (on its own it flipped a near-tie
+// pixel in a fuzz case); one Newton step brings it to ~2^-51, six orders of magnitude inside the
+// 0.5/N margin the floor needs, at a fifth of the cost of a correctly rounded division.
+__device__ __forceinline__ double rcp_nr(double c) {
+    const double r0 = __builtin_amdgcn_rcp(c);
+    return __builtin_fma(r0, __builtin_fma(-c, r0, 1.0), r0);
+}
+
 __device__ __forceinline__ bool sauvola_form_dd(double Sd, double Qd, double pxd, double rc, double hrc, bool kpos,
                                                 double km1, double k2) {
     const double mean = __builtin_floor(__builtin_fma(Sd, rc, hrc));
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
 
         // wave-uniform count / reciprocal when every output of the strip has the full window width
         const unsigned ucount = (unsigned)(P.ww * nrows);
-        const double urcd = 1.0 / (double)ucount, uhrcd = 0.5 * urcd;     // correctly rounded (v_rcp_f64 alone is a ~2^-26 seed)
+        const double urcd = rcp_nr((double)ucount), uhrcd = 0.5 * urcd;
 
         unsigned outa[KD], outb[KD];
 #pragma unroll
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             if (!full_cols) {
                 const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
                 count = (unsigned)max(ncols * nrows, 1);
-                rcd = 1.0 / (double)count;
+                rcd = rcp_nr((double)count);
                 hrcd = 0.5 * rcd;
             }
             const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
