@@ -371,6 +371,34 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     return 0;
 }
 
+// Self-test of the fp64 quotient used above: floor(fma(N, rcp_nr(c), 0.5 rcp_nr(c))) against integer
+// division for every divisor the kernel can see (1 .. 65792) and, per divisor, the dividends where a
+// quotient is most fragile: k*c - 1, k*c, k*c + 1 for ~4096 values of k spread over [0, 2^32/c).
+__global__ __launch_bounds__(256) void sauvola_div_selftest_kernel(unsigned long long *bad) {
+    const unsigned c = blockIdx.x * 256 + threadIdx.x + 1;
+    if (c > 65792u) return;
+    const double rc = rcp_nr((double)c), hrc = 0.5 * rc;
+    const unsigned long long kmax = 0xffffffffull / c;
+    const unsigned long long step = kmax / 4096 + 1;
+    unsigned long long nbad = 0;
+    for (unsigned long long k = 0; k <= kmax; k += step) {
+        for (int d = -1; d <= 1; d++) {
+            const long long N = (long long)(k * c) + d;
+            if (N < 0 || N > 0xffffffffll) continue;
+            const double q = __builtin_floor(__builtin_fma((double)(unsigned)N, rc, hrc));
+            if (q != (double)((unsigned long long)N / c)) nbad++;
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad) {
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 8, s));
+    hipLaunchKernelGGL(sauvola_div_selftest_kernel, dim3(cdiv(65792, 256)), dim3(256), 0, s, d_bad);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // jobs: host array.  For njobs > 1 (or d_jobs != nullptr) the same array must
 // already be resident at d_jobs.
 int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, const SauvolaJob *d_jobs,

@@ -182,6 +182,11 @@ int mrchip_batch_box_decisions(mrchip_batch *b, int page, int32_t *decisions, in
 int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask, size_t *mask_pitch,
                              void **fg, void **bg);
 
+/* Device self-test of the exact fp64 quotient behind mrchip_sauvola_u8 (cython/sauvola.pyx:144-145 are
+ * truncating integer divisions): every divisor 1..65792, the dividends around each multiple.
+ * *mismatches = number of (dividend, divisor) pairs whose quotient differs from integer division. */
+int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *mismatches);
+
 /* ---- measurement --------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the stream each kernel is launched on.
  * enable: 0 off, 1 on.  Kernels are named as in the kernel trace. */

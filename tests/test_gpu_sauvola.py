@@ -101,3 +101,13 @@ def test_near_tie_found_by_the_fuzzer():
     out = np.empty(h * w, np.uint8)
     sauvola.binarise_sauvola(img.reshape(-1), out, w, h, int(ww), int(wh), float(k), float(R))
     assert np.array_equal(out.reshape(h, w), z['expected'])
+
+
+def test_fp64_quotients_equal_integer_division_for_every_divisor():
+    """Device self-test: floor(fma(N, r, r/2)) with the Newton-refined reciprocal r == N // c for c = 1..65792 and
+    the dividends k*c-1, k*c, k*c+1 over the 32-bit range (~8e8 pairs)."""
+    import ctypes as C
+    from mrchip import _lib
+    bad = C.c_longlong(-1)
+    _lib.check(_lib.load().mrchip_selftest_sauvola_quotients(_lib.default_context().handle, C.byref(bad)))
+    assert bad.value == 0
