@@ -27,6 +27,20 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *
     return 0;
 }
 
+MRCHIP_EXPORT int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches) {
+    CHECK_CTX(ctx);
+    if (!mismatches) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }
+    DevBuf bad;
+    TRY(bad.alloc(ctx, 256));
+    hipStream_t s = ctx->streams[0];
+    TRY(optimise_div_selftest(ctx, s, bad.as<unsigned long long>()));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *mismatches = (long long)h;
+    return 0;
+}
+
 MRCHIP_EXPORT int mrchip_window_for_dpi(int has_dpi, double dpi) {
     int window = 51;                          // mrc.py:68
     if (has_dpi) {

@@ -900,6 +900,28 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
     } else optimise_packed_rows<C, NH, -1, DB>(J, smem);
 }
 
+// Self-test of the quotient both optimise kernels use: (unsigned)fma((float)v, rcp(cnt), rcp(cnt)/2) against
+// v / cnt for EVERY count the kernels can produce (1 .. 5120 = (2n)^2 + n^2 at n = 32) and every value
+// 0 .. 255*cnt (a window of cnt bytes): ~3.3e9 pairs.
+__global__ __launch_bounds__(256) void optimise_div_selftest_kernel(unsigned long long *bad) {
+    const unsigned cnt = blockIdx.x + 1;                     // one workgroup per count
+    const float rc = __builtin_amdgcn_rcpf((float)cnt), hrc = 0.5f * rc;
+    unsigned long long nbad = 0;
+    for (unsigned v = threadIdx.x; v <= 255u * cnt; v += 256) {
+        const unsigned q = (unsigned)__builtin_fmaf((float)v, rc, hrc);
+        if (q != v / cnt) nbad++;
+        if (div_small((int)v, rc) != v / cnt) nbad++;         // the unpacked kernel's form
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+int optimise_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad) {
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 8, s));
+    hipLaunchKernelGGL(optimise_div_selftest_kernel, dim3(5120), dim3(256), 0, s, d_bad);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 struct OptGeom { int P, T; size_t lds; };
 
 static int opt_geometry(int w, int c, int n, OptGeom *g) {

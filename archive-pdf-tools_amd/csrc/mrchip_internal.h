@@ -264,6 +264,7 @@ int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int 
                          size_t bits_stride, int npages);
 size_t denoise_scratch_bytes(int w, int h);
 int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
+int optimise_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
 // 1 bpp MSB-first rows of (w+7)/8 bytes; page i at out + i*ostride
 int launch_pack_msb(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, uint8_t *out, size_t ostride, int npages);
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     'mrchip_prof_get': (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), f64p, f64p]),
     'mrchip_hbm_copy_bandwidth': (C.c_int, [vp, C.c_size_t, C.c_int, f64p]),
     'mrchip_selftest_sauvola_quotients': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
+    'mrchip_selftest_optimise_quotients': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
 }
 
 

@@ -186,6 +186,9 @@ int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask,
  * truncating integer divisions): every divisor 1..65792, the dividends around each multiple.
  * *mismatches = number of (dividend, divisor) pairs whose quotient differs from integer division. */
 int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *mismatches);
+/* Same for mrchip_optimise's `val / cnt` (cython/optimiser.pyx:261-269): every count 1..5120 (n_size <= 32)
+ * against every value 0..255*count. */
+int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches);
 
 /* ---- measurement --------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the stream each kernel is launched on.

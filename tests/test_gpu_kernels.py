@@ -210,3 +210,12 @@ def test_hocr_mask_vs_oracle():
                                         len(boxes), O.window_size(dpi), _lib.ptr(d, _lib.i32p)))
         assert d.tolist() == dec
     assert {0, 1, 2} <= set(dec) | {0, 1, 2} and len(dec) > 0
+
+
+def test_optimise_quotient_equals_integer_division_exhaustively():
+    """Device self-test: the fp32 reciprocal quotient of both optimise kernels == val // cnt for every count
+    1..5120 and every val 0..255*cnt (3.3e9 pairs)."""
+    import ctypes as C
+    bad = C.c_longlong(-1)
+    _lib.check(_lib.load().mrchip_selftest_optimise_quotients(_lib.default_context().handle, C.byref(bad)))
+    assert bad.value == 0
