@@ -51,6 +51,7 @@ struct mrchip_batch {
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
     std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
     hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
+    int bits_valid = 0;                       // dn_bits holds the finished masks at 1 bpp (fast denoise ran)
     DevBuf packed;  int packed_valid = 0;     // 1-bpp copy of the finished masks (made on first request)
     size_t dn_stride = 0, th_bytes = 0;
     ThumbPlan plan[2];
@@ -446,6 +447,8 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N));  // :388
     b->state = 4;
     b->packed_valid = 0;
+    // the denoiser's bit rows are the final mask when its bit-sliced path ran (launch_denoise_batch)
+    b->bits_valid = denoise_fast && w > 4 && h > 4 && cdiv(w, 32) <= 512 && !getenv("MRCHIP_OPT_BYTEMASK");
     return 0;
 }
 
@@ -523,6 +526,8 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
         for (int i = 0; i < N; i++) {
             OptJob &j = hj[nj++];
             j.mask = b->mask.pl.page(i); j.mpitch = b->mask.pl.pitch;
+            j.mbits = b->bits_valid ? b->dn_bits.as<unsigned>() + (size_t)i * b->dn_stride : nullptr;
+            j.mwpr = cdiv(w, 32);
             j.img = b->img.pl.page(i); j.ipitch = b->img.pl.pitch;
             j.out = b->layer[Lr].pl.page(i); j.opitch = b->layer[Lr].pl.pitch;
             j.w = w; j.h = h;

@@ -54,6 +54,22 @@ __device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int 
     return r;
 }
 
+// Same with the mask taken from 1-bpp rows: the lane's 4 columns are one nibble of a dword that 8 lanes share
+template <int C, int P>
+__device__ __forceinline__ RowRegs<C, P> load_row_regs_bits(const unsigned *mbits, int mwpr, const uint8_t *img, int ipitch,
+                                                            int y, int h, int x0) {
+    static_assert(P == 4, "one nibble per lane");
+    RowRegs<C, P> r;
+    const int yc = min(max(y, 0), h - 1);
+    gc_u32p pm = (gc_u32p)(mbits + (size_t)yc * mwpr + (x0 >> 5));
+    gc_u32p pi = (gc_u32p)(img + (size_t)yc * ipitch + (size_t)x0 * C);
+    const unsigned word = pm[0];
+#pragma unroll
+    for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
+    r.m[0] = (((word >> (x0 & 31)) & 0xFu) * 0x00204081u) & 0x01010101u;       // bit k -> byte k = 0/1
+    return r;
+}
+
 // j-th byte of a dword array (j is a compile-time constant after unrolling: never index
 // register arrays dynamically -- hipcc 7.2 miscompiled the dynamic form at the right image edge)
 template <int N>
@@ -338,7 +354,7 @@ __device__ __forceinline__ unsigned add_dw1(unsigned a, unsigned b) {      // a 
 // every LDS access becomes `thread base + immediate offset`), or -1 for a run-time n.
 // DB: the two LDS rows are double-buffered (row y publishes into buffer y&1), which removes the
 // second barrier of a row; used when 2x the rows fit the 160 KiB of LDS.
-template <int C, int NH, int NCT, bool DB>
+template <int C, int NH, int NCT, bool DB, bool MB>
 __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem) {
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
@@ -349,6 +365,12 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int mpitch = J.mpitch, ipitch = J.ipitch, opitch = J.opitch, w = J.w, h = J.h;
     const int n = NCT >= 0 ? NCT : J.n;
     const unsigned invm = J.invert ? 0xffffffffu : 0u;
+    const unsigned *mbits = J.mbits;
+    const int mwpr = J.mwpr;
+    auto load_row = [&](int yy, int xx) {
+        if constexpr (MB) return load_row_regs_bits<C, P>(mbits, mwpr, img, ipitch, yy, h, xx);
+        else return load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, xx);
+    };
 
     const int npad = n;
     const int T = blockDim.x;
@@ -453,12 +475,12 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0);
+        RowRegs<C, P> r = load_row(yy, x0);
         fir_apply(r, true);
     }
-    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, h, x0);
-    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
-    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
+    RowRegs<C, P> r_enter = load_row(n - 1, x0);
+    RowRegs<C, P> r_leave = load_row(0, x0);
+    RowRegs<C, P> r_cur = load_row(0, x0);
     unsigned o_leave[ND];
 #pragma unroll
     for (int q = 0; q < ND; q++) o_leave[q] = 0;
@@ -466,9 +488,9 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     for (int y = 0; y < h; y++) {
         // ---- next row's loads first: independent of the serial chain ----
         const int yn = y + 1;
-        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, h, x0);
-        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, h, x0);
-        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, h, x0);
+        RowRegs<C, P> n_enter = load_row(yn + n - 1, x0);
+        RowRegs<C, P> n_leave = load_row(yn - n - 1, x0);
+        RowRegs<C, P> n_cur = load_row(yn, x0);
         unsigned n_oleave[ND];
         {
             gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)x0 * C);
@@ -892,12 +914,17 @@ template <int C, int NH, int MAXT, bool DB>
 __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const OptJob J = jobs[blockIdx.x];
-    // wave-uniform dispatch on the job's n_size: the reference's two values get unrolled bodies
-    if (J.n == 3) optimise_packed_rows<C, 1, 3, DB>(J, smem);             // fg, mrc.py:413/415 (one accumulator: n <= 8)
-    else if (J.n == 10) {
-        if constexpr (NH == 2) optimise_packed_rows<C, NH, 10, DB>(J, smem);   // bg, mrc.py:447/449
-        else optimise_packed_rows<C, NH, -1, DB>(J, smem);
-    } else optimise_packed_rows<C, NH, -1, DB>(J, smem);
+    // wave-uniform dispatch on the job's n_size (the reference's two values get unrolled bodies) and on
+    // the form of the mask (1-bpp rows from the denoiser when the job carries them)
+    if (J.mbits) {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem);            // fg, mrc.py:413/415 (one accumulator: n <= 8)
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true>(J, smem);   // bg, mrc.py:447/449
+        else optimise_packed_rows<C, NH, -1, DB, true>(J, smem);
+    } else {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, false>(J, smem);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, false>(J, smem);
+        else optimise_packed_rows<C, NH, -1, DB, false>(J, smem);
+    }
 }
 
 // Self-test of the quotient both optimise kernels use: (unsigned)fma((float)v, rcp(cnt), rcp(cnt)/2) against
