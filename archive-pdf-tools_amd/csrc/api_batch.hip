@@ -563,7 +563,20 @@ MRCHIP_EXPORT int mrchip_batch_layers(mrchip_batch *b, int which, double fg_down
     return 0;
 }
 
+static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *out, bool wait);
+
 MRCHIP_EXPORT int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_bg, uint8_t *out) {
+    return download_layer_impl(b, page, is_bg, out, true);
+}
+
+// Enqueue only: the copy runs on the batch's stream behind the kernels that produce the layer; with `out` in
+// pinned memory (mrchip_host_alloc) it is a true asynchronous DMA, so the host can hand page i to its encoder
+// while page i+1 is still being decomposed / copied.  mrchip_batch_sync before reading.
+MRCHIP_EXPORT int mrchip_batch_download_layer_async(mrchip_batch *b, int page, int is_bg, uint8_t *out) {
+    return download_layer_impl(b, page, is_bg, out, false);
+}
+
+static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *out, bool wait) {
     CHECK_B(b);
     const int Lr = is_bg ? 1 : 0;
     if (!b->layer_done[Lr]) { set_error("download_layer before layers"); return MRCHIP_E_STATE; }
@@ -575,7 +588,7 @@ MRCHIP_EXPORT int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_
     } else {
         TRY(download_2d(b->s, out, b->w * c, b->layer[Lr].pl.page(page), b->layer[Lr].pl.pitch, b->w * c, b->h));
     }
-    HIP_TRY(hipStreamSynchronize(b->s));
+    if (wait) HIP_TRY(hipStreamSynchronize(b->s));
     return 0;
 }
 

@@ -250,3 +250,18 @@ MRCHIP_EXPORT int mrchip_hbm_copy_bandwidth(mrchip_ctx *ctx, size_t bytes, int r
     *gbps = ms > 0 ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
     return 0;
 }
+
+// Pinned (page-locked) host memory for the arrays the caller hands to the *_async downloads / uploads.
+MRCHIP_EXPORT void *mrchip_host_alloc(mrchip_ctx *ctx, size_t bytes) {
+    if (!ctx || bytes == 0) { set_error("host_alloc: bad arguments"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { set_error("host_alloc: hipSetDevice failed"); return nullptr; }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_error("host_alloc: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+MRCHIP_EXPORT void mrchip_host_free(mrchip_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
+}

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -71,6 +72,9 @@ SIGNATURES = {
     'mrchip_batch_download_mask_packed': (C.c_int, [vp, C.c_int, u8p]),
     'mrchip_batch_layers': (C.c_int, [vp, C.c_int, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
     'mrchip_batch_download_layer': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
+    'mrchip_batch_download_layer_async': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
+    'mrchip_host_alloc': (C.c_void_p, [vp, C.c_size_t]),
+    'mrchip_host_free': (None, [vp, C.c_void_p]),
     'mrchip_batch_sync': (C.c_int, [vp]),
     'mrchip_batch_box_decisions': (C.c_int, [vp, C.c_int, i32p, C.c_int]),
     'mrchip_batch_device_ptrs': (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t),
@@ -147,6 +151,20 @@ class Context:
         hbm = C.c_size_t()
         check(load().mrchip_device_info(self.handle, name, 128, C.byref(cus), C.byref(hbm)))
         return {'name': name.value.decode(), 'cus': cus.value, 'hbm_bytes': hbm.value}
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array over page-locked host memory (freed with the array): the destination of the
+        asynchronous downloads (Batch.download_layer(..., out=..., wait=False))."""
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        lib = load()
+        p = lib.mrchip_host_alloc(self.handle, max(nbytes, 1))
+        if not p:
+            raise MrchipError('mrchip_host_alloc(%d) failed: %s' % (nbytes, last_error()))
+        buf = (C.c_ubyte * max(nbytes, 1)).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        weakref.finalize(buf, lib.mrchip_host_free, None, p)      # hipHostFree needs no particular device
+        return arr
 
     def hbm_copy_bandwidth(self, nbytes=1 << 30, reps=10):
         """Measured device-to-device copy rate in GB/s (bytes read + written)."""

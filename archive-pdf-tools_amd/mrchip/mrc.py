@@ -288,11 +288,18 @@ class Batch:
                    'mrchip_batch_download_mask_packed')
         return out
 
-    def download_layer(self, page, is_bg, size):
+    def download_layer(self, page, is_bg, size, out=None, wait=True):
+        """fg (is_bg=0) / bg layer of one page.  `out`: destination array (e.g. Context.pinned_empty); with
+        wait=False the copy is only enqueued (call sync() before reading) so the host can encode page i while
+        page i+1 is still being copied / decomposed."""
         ow, oh = size
-        out = np.empty((oh, ow) if self.c == 1 else (oh, ow, 3), dtype=np.uint8)
-        _lib.check(self.lib.mrchip_batch_download_layer(self._h, page, 1 if is_bg else 0, _lib.ptr(out)),
-                   'mrchip_batch_download_layer')
+        shape = (oh, ow) if self.c == 1 else (oh, ow, 3)
+        if out is None:
+            out = np.empty(shape, dtype=np.uint8)
+        elif out.shape != shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError('download_layer: out must be a C-contiguous uint8 array of shape %r' % (shape,))
+        fn = self.lib.mrchip_batch_download_layer if wait else self.lib.mrchip_batch_download_layer_async
+        _lib.check(fn(self._h, page, 1 if is_bg else 0, _lib.ptr(out)), 'mrchip_batch_download_layer')
         return out
 
     def box_decisions(self, page, nb):
@@ -444,3 +451,17 @@ def thumbnail(arr, size, resample='bicubic', reducing_gap=2.0, ctx=None):
     _lib.check(lib.mrchip_thumbnail_ex(ctx.handle, _lib.ptr(a), w, h, c, rw, rh, _FILTERS[resample],
                                        float(reducing_gap) if reducing_gap else 0.0, _lib.ptr(out)), 'mrchip_thumbnail_ex')
     return out
+
+
+def layer_to_pnm(arr):
+    """Binary PGM (P5) / PPM (P6) file bytes of a uint8 layer -- what `Image.fromarray(arr).save('x.pnm')`
+    writes and what the JPEG2000 encoders of mrc.encode_mrc_images read (mrc.py:523-580, jpeg2000.py:44-84)
+    -- without the PIL round trip."""
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.ndim == 2:
+        head = b'P5\n%d %d\n255\n' % (a.shape[1], a.shape[0])
+    elif a.ndim == 3 and a.shape[2] == 3:
+        head = b'P6\n%d %d\n255\n' % (a.shape[1], a.shape[0])
+    else:
+        raise ValueError('layer_to_pnm: uint8[H,W] or uint8[H,W,3] expected')
+    return head + a.tobytes()

@@ -227,6 +227,18 @@ def main():
                                                     denoise_mask='fast', ctx=ctx):
                 pass
         extra['pcie_inclusive_pages_per_s'] = round(reps / (time.perf_counter() - t1), 2)
+        # layer hand-off: D2H rate of one full-resolution layer, pageable vs pinned destination
+        try:
+            pg = np.empty((H, W, C), np.uint8)
+            pin = ctx.pinned_empty((H, W, C))
+            for name, dstarr in (('pageable', pg), ('pinned', pin)):
+                batch.download_layer(0, 0, (W, H), out=dstarr)
+                t2 = time.perf_counter()
+                for _ in range(3):
+                    batch.download_layer(0, 0, (W, H), out=dstarr)
+                extra['d2h_layer_GBps_' + name] = round(3 * pg.nbytes / (time.perf_counter() - t2) / 1e9, 1)
+        except Exception as e:     # pragma: no cover
+            extra['d2h_layer_GBps_error'] = str(e)
         # measured ceiling to read the roofline fractions against: D2D copy, read + write bytes
         extra['hbm_copy_GBps_measured'] = round(ctx.hbm_copy_bandwidth(1 << 30, 10), 1)
 

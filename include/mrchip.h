@@ -57,6 +57,10 @@ int mrchip_sync(mrchip_ctx *ctx);
 /* Device name / CU count of the context's device (for reports). */
 int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes);
 
+/* Page-locked host memory for buffers handed to the *_async entry points (NULL on failure). */
+void *mrchip_host_alloc(mrchip_ctx *ctx, size_t bytes);
+void mrchip_host_free(mrchip_ctx *ctx, void *p);
+
 /* ---- cython/sauvola.pyx -------------------------------------------------- */
 /* sauvola.binarise_sauvola(in_arr, out_arr, width, height, window_width,
  * window_height, k, R) -- cython/sauvola.pyx:29-222.  in/out are flat
@@ -177,6 +181,11 @@ int mrchip_batch_download_mask_packed(mrchip_batch *b, int page, uint8_t *packed
 int mrchip_batch_layers(mrchip_batch *b, int which, double fg_downsample, double bg_downsample,
                         int *fg_w, int *fg_h, int *bg_w, int *bg_h, int *too_small);
 int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_bg, uint8_t *out);
+/* fg/bg hand-off to the image encoders (mrc.py:523-580 writes each layer to a file for kdu/opj/grok;
+ * SURVEY.md 8f rank 2): enqueue-only copy on the batch's stream -- a true asynchronous DMA when `out` is
+ * pinned (mrchip_host_alloc) -- so page i can go to its encoder while page i+1 is still on the device.
+ * mrchip_batch_sync before the bytes are read. */
+int mrchip_batch_download_layer_async(mrchip_batch *b, int page, int is_bg, uint8_t *out);
 int mrchip_batch_sync(mrchip_batch *b);
 int mrchip_batch_box_decisions(mrchip_batch *b, int page, int32_t *decisions, int nb);
 int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask, size_t *mask_pitch,

@@ -62,3 +62,42 @@ def test_packed_mask_matches_numpy_packbits_and_pil():
             b = Image.fromarray(mask)
             assert a.mode == b.mode == '1' and a.tobytes() == b.tobytes()
         bt.close()
+
+
+def test_async_layer_downloads_into_pinned_memory_and_pnm_bytes():
+    """layers leave through pinned buffers with enqueue-only copies (encode page i while
+    page i+1 is in flight); layer_to_pnm == what PIL writes for the JPEG2000 encoders."""
+    import io
+    ctx = _lib.default_context()
+    w, h = 333, 217
+    for c in (1, 3):
+        pages = [synth.synth_page(w, h, c, seed=70 + i, noise_sigma=5.0, line_div=10) for i in range(3)]
+        bt = mrc.Batch(ctx, 3, w, h, c)
+        for i, (img, hocr) in enumerate(pages):
+            bt.upload(i, img)
+            bt.set_boxes(i, mrc.hocr_boxes(hocr, w, h))
+        bt.mask_begin(51)
+        bt.mask_finish(bt.sigmas(), True)
+        fgs, bgs, _ = bt.layers(None, 3)
+        pinned = [(ctx.pinned_empty((fgs[1], fgs[0]) if c == 1 else (fgs[1], fgs[0], 3)),
+                   ctx.pinned_empty((bgs[1], bgs[0]) if c == 1 else (bgs[1], bgs[0], 3))) for _ in range(3)]
+        for i in range(3):                                   # all six copies enqueued, one wait
+            bt.download_layer(i, 0, fgs, out=pinned[i][0], wait=False)
+            bt.download_layer(i, 1, bgs, out=pinned[i][1], wait=False)
+        bt.sync()
+        for i in range(3):
+            assert np.array_equal(pinned[i][0], bt.download_layer(i, 0, fgs))
+            assert np.array_equal(pinned[i][1], bt.download_layer(i, 1, bgs))
+            e = O.create_mrc_hocr_components(pages[i][0], pages[i][1], denoise_mask='fast', bg_downsample=3)
+            next(e)
+            assert np.array_equal(pinned[i][0], next(e)) and np.array_equal(pinned[i][1], next(e))
+        pnm = mrc.layer_to_pnm(pinned[0][1])
+        try:
+            from PIL import Image
+        except ImportError:
+            Image = None
+        if Image is not None:
+            f = io.BytesIO()
+            Image.fromarray(np.array(pinned[0][1])).save(f, format='PPM')
+            assert f.getvalue() == pnm
+        bt.close()
