@@ -46,9 +46,30 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     return 0;
 }
 
+// Returned blocks stay cached for reuse (hipMalloc / hipFree synchronise the device); the cache is trimmed,
+// largest idle block first, once the idle bytes exceed MRCHIP_CACHE_BYTES (default 16 GiB) so that a long
+// run over many page sizes does not sit on the whole HBM.
 void dev_free(mrchip_ctx *ctx, void *p) {
-    for (auto &b : ctx->blocks)
-        if (b.base == p) { b.busy = false; return; }
+    static const size_t cap = getenv("MRCHIP_CACHE_BYTES") ? (size_t)atoll(getenv("MRCHIP_CACHE_BYTES")) : ((size_t)16 << 30);
+    size_t idle = 0;
+    for (auto &b : ctx->blocks) {
+        if (b.base == p) b.busy = false;
+        if (!b.busy && b.base) idle += b.bytes;
+    }
+    while (idle > cap) {
+        int big = -1;
+        for (size_t i = 0; i < ctx->blocks.size(); i++)
+            if (!ctx->blocks[i].busy && ctx->blocks[i].base && (big < 0 || ctx->blocks[i].bytes > ctx->blocks[big].bytes)) big = (int)i;
+        if (big < 0) break;
+        (void)hipFree(ctx->blocks[big].base);
+        idle -= ctx->blocks[big].bytes;
+        ctx->blocks[big].base = nullptr; ctx->blocks[big].bytes = 0;
+    }
+    // forget released entries
+    size_t k = 0;
+    for (size_t i = 0; i < ctx->blocks.size(); i++)
+        if (ctx->blocks[i].base) ctx->blocks[k++] = ctx->blocks[i];
+    ctx->blocks.resize(k);
 }
 
 int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
