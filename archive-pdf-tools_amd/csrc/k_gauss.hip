@@ -106,10 +106,17 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
         if (g < ngroups && sgm < GF_TH / GF_SEG) {
             const int x = Xa + 4 * g, y0 = Y0 + sgm * GF_SEG;
             unsigned in[GF_SEG + 2 * R];
+            if (Y0 - R >= 0 && Y0 + GF_TH + R <= h) {
+                // tile away from the top / bottom border (workgroup-uniform): consecutive rows, no reflection
+                const uint8_t *p = src + (size_t)(y0 - R) * spitch + x;
 #pragma unroll
-            for (int i = 0; i < GF_SEG + 2 * R; i++) {
-                const int yy = reflect_idx(min(y0 - R + i, h - 1 + R), h);   // rows past the tile's last row are unused
-                in[i] = *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x);
+                for (int i = 0; i < GF_SEG + 2 * R; i++) in[i] = *reinterpret_cast<const unsigned *>(p + (size_t)i * spitch);
+            } else {
+#pragma unroll
+                for (int i = 0; i < GF_SEG + 2 * R; i++) {
+                    const int yy = reflect_idx(min(y0 - R + i, h - 1 + R), h);   // rows past the tile's last row are unused
+                    in[i] = *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x);
+                }
             }
 #pragma unroll
             for (int k = 0; k < GF_SEG; k++) {
