@@ -312,29 +312,39 @@ class Batch:
 
 
 def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
-                    denoise_mask=DENOISE_FAST, ctx=None):
-    """Batch form of create_mrc_hocr_components for same-sized pages: returns a list of
-    (mask, fg, bg) tuples equal to what the generator yields page by page."""
+                    denoise_mask=DENOISE_FAST, ctx=None, max_batch_bytes=64 << 30):
+    """Batch form of create_mrc_hocr_components: returns a list of (mask, fg, bg) tuples equal to what the
+    generator yields page by page, in input order.  Pages are grouped by (width, height, mode) -- a device
+    batch holds pages of one size -- and each group is cut into batches of at most `max_batch_bytes` of
+    device memory."""
     arrs = [_image_to_array(im) for im in images]
-    h, w = arrs[0].shape[:2]
-    c = 1 if arrs[0].ndim == 2 else 3
+    if len(arrs) != len(hocr_list):
+        raise ValueError('decompose_pages: one hOCR page per image expected')
     if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
         raise ValueError('Invalid denoise option:', denoise_mask)
     ctx = ctx or _lib.default_context()
-    b = Batch(ctx, len(arrs), w, h, c)
-    try:
-        for i, (a, hocr) in enumerate(zip(arrs, hocr_list)):
-            if a.shape[:2] != (h, w) or (1 if a.ndim == 2 else 3) != c:
-                raise ValueError('decompose_pages needs same-sized pages of one mode')
-            b.upload(i, a)
-            b.set_boxes(i, hocr_boxes(hocr, w, h, downsample))
-        b.mask_begin(_window_size(dpi))
-        b.mask_finish(b.sigmas(), denoise_mask == DENOISE_FAST)
-        fgs, bgs, _ = b.layers(fg_downsample, bg_downsample)
-        return [(b.download_mask(i), b.download_layer(i, 0, fgs), b.download_layer(i, 1, bgs))
-                for i in range(len(arrs))]
-    finally:
-        b.close()
+    groups = {}
+    for i, a in enumerate(arrs):
+        groups.setdefault((a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3), []).append(i)
+    out = [None] * len(arrs)
+    for (h, w, c), idx in groups.items():
+        per_page = w * h * (10 + 6 * c) + (4 << 20)          # planes of a page in a batch (DESIGN.md 2)
+        step = max(1, int(max_batch_bytes // per_page))
+        for k in range(0, len(idx), step):
+            part = idx[k:k + step]
+            b = Batch(ctx, len(part), w, h, c)
+            try:
+                for j, i in enumerate(part):
+                    b.upload(j, arrs[i])
+                    b.set_boxes(j, hocr_boxes(hocr_list[i], w, h, downsample))
+                b.mask_begin(_window_size(dpi))
+                b.mask_finish(b.sigmas(), denoise_mask == DENOISE_FAST)
+                fgs, bgs, _ = b.layers(fg_downsample, bg_downsample)
+                for j, i in enumerate(part):
+                    out[i] = (b.download_mask(j), b.download_layer(j, 0, fgs), b.download_layer(j, 1, bgs))
+            finally:
+                b.close()
+    return out
 
 
 def _image_to_array(image):

@@ -101,3 +101,16 @@ def test_async_layer_downloads_into_pinned_memory_and_pnm_bytes():
             Image.fromarray(np.array(pinned[0][1])).save(f, format='PPM')
             assert f.getvalue() == pnm
         bt.close()
+
+
+def test_decompose_pages_groups_mixed_sizes_and_modes():
+    """a book's pages differ in size and mode: decompose_pages groups them into same-size batches and returns the
+    results in input order"""
+    specs = [(320, 200, 3), (200, 320, 1), (320, 200, 3), (64, 48, 3), (200, 320, 1), (320, 200, 1)]
+    pages = [synth.synth_page(w, h, c, seed=90 + i, noise_sigma=4.0, line_div=9) for i, (w, h, c) in enumerate(specs)]
+    res = mrc.decompose_pages([p[0] for p in pages], [p[1] for p in pages], bg_downsample=2, max_batch_bytes=3 << 20)
+    for (img, hocr), got in zip(pages, res):
+        e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', bg_downsample=2)
+        for a in got:
+            b = next(e)
+            assert a.shape == b.shape and np.array_equal(a, b)
