@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity sweep (kernel entry points and whole-page decompositions over random
 shapes / windows / k / n_size / downsample factors / hOCR boxes).  Not part of the pytest suite (minutes);
-run on a GPU box:  python tools/fuzz_parity.py [seconds] [seed]"""
+run on a GPU box:  python tests/fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))

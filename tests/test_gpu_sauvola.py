@@ -90,7 +90,7 @@ def test_config_sizes_digest_and_property():
 
 
 def test_near_tie_found_by_the_fuzzer():
-    """tools/fuzz_parity.py case: at pixel (31, 67) Q/count = 52231.9987 and the decision's two sides differ by
+    """tests/fuzz_parity.py case: at pixel (31, 67) Q/count = 52231.9987 and the decision's two sides differ by
     4e-4 relative, so a quotient off by one flips the pixel.  (The hardware fp64 reciprocal alone is a ~2^-26
     seed and did exactly that; the kernel divides with a correctly rounded 1/count.)"""
     import os
