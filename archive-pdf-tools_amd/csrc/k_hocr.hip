@@ -13,46 +13,50 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
     uint8_t *mask = B.mask;
     const int mpitch = B.mpitch, nb = B.page_end;
     const int bh = B.b - B.t;
-    // one lane per 4 pixels, dword-aligned in the MASK's coordinates (the box scratch has the
+    // one lane per 16 pixels (four dwords), dword-aligned in the MASK's coordinates (the box scratch has the
     // same column phase mod 16, so its dwords line up too)
-    const int xa = (B.l & ~3) + (blockIdx.x * 256 + threadIdx.x) * 4;     // absolute column of the dword
-    if (xa >= B.r) return;
+    const int xa0 = (B.l & ~3) + (blockIdx.x * 256 + threadIdx.x) * 16;   // absolute column of the first dword
+    if (xa0 >= B.r) return;
     const uint8_t *th = B.decision == 1 ? B.th : B.thi;
-    // later boxes with a decision that intersect this column group (wave-uniform scalar loop)
     for (int y = blockIdx.y; y < bh; y += gridDim.y) {
         const int py = B.t + y;
-        unsigned keep = 0;                       // byte mask of pixels this box owns
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int px = xa + i;
-            if (px >= B.l && px < B.r) keep |= 0xffu << (8 * i);
-        }
-        if (B.overlapped) {                      // rare: some later box with a decision intersects this one
-            for (int j = b + 1; j < nb; j++) {
-                const HocrBox &L = boxes[j];
-                if (L.decision == 0 || py < L.t || py >= L.b) continue;
+        for (int q = 0; q < 4; q++) {
+            const int xa = xa0 + 4 * q;
+            if (xa >= B.r) break;
+            unsigned keep = 0;                       // byte mask of pixels this box owns
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int px = xa + i;
-                    if (px >= L.l && px < L.r) keep &= ~(0xffu << (8 * i));
+            for (int i = 0; i < 4; i++) {
+                const int px = xa + i;
+                if (px >= B.l && px < B.r) keep |= 0xffu << (8 * i);
+            }
+            if (B.overlapped) {                      // rare: some later box with a decision intersects this one
+                for (int j = b + 1; j < nb; j++) {
+                    const HocrBox &L = boxes[j];
+                    if (L.decision == 0 || py < L.t || py >= L.b) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int px = xa + i;
+                        if (px >= L.l && px < L.r) keep &= ~(0xffu << (8 * i));
+                    }
                 }
             }
-        }
-        if (!keep) continue;
-        const unsigned v = *reinterpret_cast<const unsigned *>(th + (ptrdiff_t)y * B.pitch + (xa - B.l));
-        uint8_t *mp = mask + (size_t)py * mpitch + xa;
-        // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel
-        // has exactly one owner (box, lane), so the read-modify-write is race-free
-        if (keep == 0xffffffffu) {
-            unsigned *mq = reinterpret_cast<unsigned *>(mp);
-            *mq = or_mode ? (*mq | v) : v;
-        } else {      // partial dword: byte accesses, so that a neighbouring box's bytes are never rewritten
+            if (!keep) continue;
+            const unsigned v = *reinterpret_cast<const unsigned *>(th + (ptrdiff_t)y * B.pitch + (xa - B.l));
+            uint8_t *mp = mask + (size_t)py * mpitch + xa;
+            // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel
+            // has exactly one owner (box, lane), so the read-modify-write is race-free
+            if (keep == 0xffffffffu) {
+                unsigned *mq = reinterpret_cast<unsigned *>(mp);
+                *mq = or_mode ? (*mq | v) : v;
+            } else {      // partial dword: byte accesses, so that a neighbouring box's bytes are never rewritten
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if ((keep >> (8 * i)) & 0xffu) {
-                    const uint8_t bv = (uint8_t)(v >> (8 * i));
-                    mp[i] = or_mode ? (uint8_t)(mp[i] | bv) : bv;
-                }
+                for (int i = 0; i < 4; i++)
+                    if ((keep >> (8 * i)) & 0xffu) {
+                        const uint8_t bv = (uint8_t)(v >> (8 * i));
+                        mp[i] = or_mode ? (uint8_t)(mp[i] | bv) : bv;
+                    }
+            }
         }
     }
 }
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
                        int or_mode) {
     if (nb <= 0) return 0;
-    dim3 grid(cdiv(cdiv(maxw + 3, 4), 256), std::min(maxh, 64), nb);
+    dim3 grid(cdiv(cdiv(maxw + 3, 16), 256), std::min(maxh, 64), nb);
     LAUNCH(ctx, s, "hocr_commit", (or_mode ? 3.0 : 2.0) * area,
            hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes, or_mode));
     return 0;
