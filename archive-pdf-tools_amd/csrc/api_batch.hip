@@ -44,6 +44,7 @@ struct mrchip_batch {
     mrchip_ctx *ctx = nullptr;
     hipStream_t s = nullptr;
     int n = 0, w = 0, h = 0, c = 1;
+    int active = 0;                  // pages in use (<= n): what every stage launch covers (mrchip_batch_set_count)
     PlaneBuf img, gray_own, blur, mask, layer[2], small[2], sc1[2], sc2[2];
     Plane gray;
     DevBuf gtmp;  int gtmp_pitch = 0;  size_t gtmp_stride = 0;     // float32 scratch of the blur
@@ -67,6 +68,12 @@ struct mrchip_batch {
     std::vector<double> sigma;
     int window = 51;
     int state = 0;    // 0 created, 1 uploaded, 2 mask_begin, 3 sigma known, 4 mask done
+    // The control block is laid out for nb_cap boxes, a capacity that only grows (with a stream
+    // synchronisation): the offsets of its regions then stay put from step to step, so a region is only
+    // rewritten after the host has waited for the stream at least once since its last copy was queued
+    // (mrchip_batch_sigmas sits between any two writes of the same region).
+    int nb_cap = 0;
+    std::vector<char> gray_given;     // per page: the caller supplied the gray plane (mrchip_batch_upload_gray)
 };
 
 // control block layout (device + pinned mirror)
@@ -98,7 +105,7 @@ struct CtrlLayout {
 static int batch_init(mrchip_batch *b, mrchip_ctx *ctx, int npages, int w, int h, int c) {
     b->ctx = ctx;
     b->s = ctx->streams[ctx->next_stream++ % NSTREAMS];
-    b->n = npages; b->w = w; b->h = h; b->c = c;
+    b->n = npages; b->active = npages; b->w = w; b->h = h; b->c = c;
     TRY(b->img.alloc(ctx, npages, w * c, h));
     if (c == 3) TRY(b->gray_own.alloc(ctx, npages, w, h));
     TRY(b->mask.alloc(ctx, npages, w, h));
@@ -116,6 +123,7 @@ static int batch_init(mrchip_batch *b, mrchip_ctx *ctx, int npages, int w, int h
     b->dn_stride = (denoise_scratch_bytes(w, h) + 3) / 4;
     TRY(b->dn_bits.alloc(ctx, b->dn_stride * 4 * npages));
     b->page_boxes.resize(npages);
+    b->gray_given.assign(npages, 0);
     b->sigma.assign(npages, 0.0);
     return 0;
 }
@@ -140,12 +148,57 @@ MRCHIP_EXPORT void mrchip_batch_destroy(mrchip_batch *b) {
     delete b;
 }
 
+// new pixels or boxes: everything derived from the previous ones is stale (mask, 1-bpp rows, layers)
+static void invalidate_results(mrchip_batch *b) {
+    b->state = 1;
+    b->bits_valid = 0;
+    b->packed_valid = 0;
+    b->layer_done[0] = b->layer_done[1] = 0;
+}
+
 MRCHIP_EXPORT int mrchip_batch_upload(mrchip_batch *b, int page, const uint8_t *img) {
     CHECK_B(b);
     if (!img || page < 0 || page >= b->n) { set_error("batch_upload: bad arguments"); return MRCHIP_E_ARG; }
     TRY(upload_2d(b->s, b->img.pl.page(page), b->img.pl.pitch, img, b->w * b->c, b->w * b->c, b->h));
-    if (b->state < 1) b->state = 1;
+    invalidate_results(b);
+    b->gray_given[page] = 0;
+    return 0;
+}
+
+// Gray plane of an RGB batch page computed by the caller: create_mrc_hocr_components takes
+// `image.convert('L')` of the ORIGINAL image (mrc.py:359-361) and only later converts modes other than
+// L / RGB to RGB for the layers (mrc.py:401-404); for those modes Pillow's L conversion is not the luma of
+// the RGB conversion, so the mirror uploads both.  Call after mrchip_batch_upload of the same page.
+MRCHIP_EXPORT int mrchip_batch_upload_gray(mrchip_batch *b, int page, const uint8_t *gray) {
+    CHECK_B(b);
+    if (!gray || page < 0 || page >= b->n) { set_error("batch_upload_gray: bad arguments"); return MRCHIP_E_ARG; }
+    if (b->c != 3) { set_error("batch_upload_gray: the batch is gray already (upload the page itself)"); return MRCHIP_E_ARG; }
+    TRY(upload_2d(b->s, b->gray_own.pl.page(page), b->gray_own.pl.pitch, gray, b->w, b->w, b->h));
+    invalidate_results(b);
+    b->gray_given[page] = 1;
+    return 0;
+}
+
+// Replace the finished mask of a page (uint8/bool[h][w]) before the layers are made: the hook for mask
+// post-processing that stays on the host, i.e. denoise_mask='bregman' (mrc.py:391-392, scikit-image's
+// iterative TV solver; SURVEY.md 8f rank 4 keeps it a CPU passthrough).
+MRCHIP_EXPORT int mrchip_batch_upload_mask(mrchip_batch *b, int page, const uint8_t *mask) {
+    CHECK_B(b);
+    if (!mask || page < 0 || page >= b->n) { set_error("batch_upload_mask: bad arguments"); return MRCHIP_E_ARG; }
+    if (b->state < 4) { set_error("upload_mask before mask_finish"); return MRCHIP_E_STATE; }
+    TRY(upload_2d(b->s, b->mask.pl.page(page), b->mask.pl.pitch, mask, b->w, b->w, b->h));
+    b->bits_valid = 0;          // the denoiser's 1-bpp rows no longer describe the mask
+    b->packed_valid = 0;
     b->layer_done[0] = b->layer_done[1] = 0;
+    return 0;
+}
+
+// Number of pages in use, 1..npages (default npages): a streaming caller reuses one batch object for a short
+// last batch; pages >= count are neither read nor written by any stage.
+MRCHIP_EXPORT int mrchip_batch_set_count(mrchip_batch *b, int count) {
+    CHECK_B(b);
+    if (count < 1 || count > b->n) { set_error("batch_set_count: %d is outside 1..%d", count, b->n); return MRCHIP_E_ARG; }
+    if (count != b->active) { b->active = count; invalidate_results(b); }
     return 0;
 }
 
@@ -161,15 +214,16 @@ MRCHIP_EXPORT int mrchip_batch_set_boxes(mrchip_batch *b, int page, const int32_
         }
     }
     b->page_boxes[page].assign(boxes, boxes + (size_t)4 * nb);
+    if (b->state > 1) invalidate_results(b);
     return 0;
 }
 
 static int ensure_ctrl(mrchip_batch *b, int nb) {
-    size_t need = CtrlLayout(b->n, nb).total;
-    if (need > b->ctrl_bytes) {
+    if (nb > b->nb_cap || !b->hctrl) {
         HIP_TRY(hipStreamSynchronize(b->s));
+        b->nb_cap = std::max(nb + nb / 2, 64);
+        const size_t need = (CtrlLayout(b->n, b->nb_cap).total + 4095) & ~(size_t)4095;
         if (b->hctrl) { HIP_TRY(hipHostFree(b->hctrl)); b->hctrl = nullptr; }
-        need = (need * 2 + 4095) & ~(size_t)4095;
         TRY(b->ctrl.alloc(b->ctx, need));
         HIP_TRY(hipHostMalloc((void **)&b->hctrl, need, hipHostMallocDefault));
         b->ctrl_bytes = need;
@@ -183,9 +237,19 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
     if (window < 1) { set_error("mask_begin: bad window"); return MRCHIP_E_ARG; }
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
-    const int w = b->w, h = b->h, N = b->n;
+    const int w = b->w, h = b->h, N = b->active;
     b->window = window;
-    if (b->c == 3) TRY(launch_luma601(ctx, s, b->img.pl, b->gray_own.pl, w, h, N));                       // mrc.py:361
+    if (b->c == 3) {                                                                                     // mrc.py:361
+        for (int i = 0; i < N;) {          // runs of pages that have no caller-supplied gray plane
+            if (b->gray_given[i]) { i++; continue; }
+            int e = i;
+            while (e < N && !b->gray_given[e]) e++;
+            Plane src = b->img.pl, dst = b->gray_own.pl;
+            src.p = src.page(i); dst.p = dst.page(i);
+            TRY(launch_luma601(ctx, s, src, dst, w, h, e - i));
+            i = e;
+        }
+    }
     // mask_arr = zeros (mrc.py:367) is never materialised: the page threshold is stored first and the hOCR
     // boxes are OR-ed on top (mask_finish), which is the same set of pixels as commit-then-OR (mrc.py:266, 329)
     // ---- hOCR boxes of all pages: both polarities + counts ----
@@ -209,7 +273,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
     const int nb = (int)b->boxes.size();
     b->first_box[N] = nb;
     TRY(ensure_ctrl(b, nb));
-    const CtrlLayout L(N, nb);
+    const CtrlLayout L(b->n, b->nb_cap);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
     if (nb > 0) {
         if (off + 4096 > b->th_bytes) {
@@ -258,7 +322,7 @@ MRCHIP_EXPORT int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est) {
     CHECK_B(b);
     if (b->state < 2) { set_error("sigmas before mask_begin"); return MRCHIP_E_STATE; }
     HIP_TRY(hipStreamSynchronize(b->s));
-    const CtrlLayout L(b->n, (int)b->boxes.size());
+    const CtrlLayout L(b->n, b->nb_cap);
     const double *hs = reinterpret_cast<const double *>(b->hctrl + L.sigma);
     for (int i = 0; i < b->n; i++) {
         b->sigma[i] = hs[i];
@@ -280,7 +344,7 @@ static int box_decisions_begin(mrchip_batch *b) {
     if (nb == 0) return 0;
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
-    const CtrlLayout L(b->n, nb);
+    const CtrlLayout L(b->n, b->nb_cap);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
     const unsigned *counts = reinterpret_cast<const unsigned *>(b->hctrl + L.counts);
     std::vector<int> &need = b->need;          // boxes on the sigma path
@@ -338,7 +402,7 @@ static int box_decisions_commit(mrchip_batch *b, int or_mode) {
     if (nb == 0) return 0;
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
-    const CtrlLayout L(b->n, nb);
+    const CtrlLayout L(b->n, b->nb_cap);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
     const std::vector<int> &need = b->need;
     const std::vector<double> &ratio = b->ratio, &inv_ratio = b->inv_ratio;
@@ -391,8 +455,8 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     if (b->state == 2) TRY(mrchip_batch_sigmas(b, nullptr));
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
-    const int w = b->w, h = b->h, N = b->n, nb = (int)b->boxes.size();
-    const CtrlLayout L(N, nb);
+    const int w = b->w, h = b->h, N = b->active;
+    const CtrlLayout L(b->n, b->nb_cap);
     unsigned char *dctrl = b->ctrl.as<unsigned char>();
     TRY(box_decisions_begin(b));          // box sigma jobs go first; their results are awaited after the page threshold is queued
     // ---- create_threshold_mask (mrc.py:300-329) ----
@@ -452,31 +516,94 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     return 0;
 }
 
-MRCHIP_EXPORT int mrchip_batch_download_mask(mrchip_batch *b, int page, uint8_t *mask) {
+// mrc.threshold_image (mrc.py:58-87) of every page of the batch in one launch: Sauvola with a square window on
+// the gray plane (the luma of an RGB page), True = dark stored into the mask plane; afterwards the mask can be
+// downloaded like a finished one.  The Sauvola-only workload of BASELINE.json configs[2].
+MRCHIP_EXPORT int mrchip_batch_threshold(mrchip_batch *b, int window, double k) {
+    CHECK_B(b);
+    if (b->state < 1) { set_error("threshold before upload"); return MRCHIP_E_STATE; }
+    if (window < 1) { set_error("threshold: bad window"); return MRCHIP_E_ARG; }
+    mrchip_ctx *ctx = b->ctx;
+    hipStream_t s = b->s;
+    const int N = b->active;
+    TRY(ensure_ctrl(b, 0));
+    const CtrlLayout L(b->n, b->nb_cap);
+    if (b->c == 3) {
+        for (int i = 0; i < N; i++)
+            if (b->gray_given[i]) { set_error("threshold: caller-supplied gray planes are a create_mrc_hocr_components feature"); return MRCHIP_E_ARG; }
+        TRY(launch_luma601(ctx, s, b->img.pl, b->gray_own.pl, b->w, b->h, N));
+    }
+    SauvolaJob *hj = reinterpret_cast<SauvolaJob *>(b->hctrl + L.pjobs);
+    SauvolaJob *dj = reinterpret_cast<SauvolaJob *>(b->ctrl.as<unsigned char>() + L.pjobs);
+    HIP_TRY(hipStreamSynchronize(s));           // the job array's previous copy may still be queued (no sigmas() in this flow)
+    for (int i = 0; i < N; i++) {
+        hj[i].src = b->gray.page(i); hj[i].src_pitch = b->gray.pitch;
+        hj[i].w = b->w; hj[i].h = b->h;
+        hj[i].dst = b->mask.pl.page(i); hj[i].dst_pitch = b->mask.pl.pitch;
+        hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
+    }
+    HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
+    TRY(launch_sauvola_dev(ctx, s, hj, dj, N, window, window, k, 128.0, SAUVOLA_INVERT));
+    b->state = 4;
+    b->bits_valid = 0;
+    b->packed_valid = 0;
+    b->layer_done[0] = b->layer_done[1] = 0;
+    return 0;
+}
+
+static int download_mask_impl(mrchip_batch *b, int page, uint8_t *mask, bool wait) {
     CHECK_B(b);
     if (b->state < 4) { set_error("download_mask before mask_finish"); return MRCHIP_E_STATE; }
     if (page < 0 || page >= b->n || !mask) { set_error("download_mask: bad arguments"); return MRCHIP_E_ARG; }
     TRY(download_2d(b->s, mask, b->w, b->mask.pl.page(page), b->mask.pl.pitch, b->w, b->h));
-    HIP_TRY(hipStreamSynchronize(b->s));
+    if (wait) HIP_TRY(hipStreamSynchronize(b->s));
     return 0;
+}
+
+MRCHIP_EXPORT int mrchip_batch_download_mask(mrchip_batch *b, int page, uint8_t *mask) {
+    return download_mask_impl(b, page, mask, true);
+}
+// enqueue only (see mrchip_batch_download_layer_async)
+MRCHIP_EXPORT int mrchip_batch_download_mask_async(mrchip_batch *b, int page, uint8_t *mask) {
+    return download_mask_impl(b, page, mask, false);
 }
 
 // The mask as the encoder wants it (mrc.py:474-520 makes a PIL mode '1' image of it): 1 bit per
 // pixel, MSB first, (w+7)/8 bytes per row -- an eighth of the bytes over PCIe.
-MRCHIP_EXPORT int mrchip_batch_download_mask_packed(mrchip_batch *b, int page, uint8_t *out) {
+static int download_mask_packed_impl(mrchip_batch *b, int page, uint8_t *out, bool wait) {
     CHECK_B(b);
     if (b->state < 4) { set_error("download_mask_packed before mask_finish"); return MRCHIP_E_STATE; }
     if (page < 0 || page >= b->n || !out) { set_error("download_mask_packed: bad arguments"); return MRCHIP_E_ARG; }
     const size_t per_page = ((size_t)((b->w + 7) / 8) * b->h + 255) & ~(size_t)255;
     if (!b->packed_valid) {
-        if (!b->packed.p) TRY(b->packed.alloc(b->ctx, per_page * b->n + 256));
-        TRY(launch_pack_msb(b->ctx, b->s, b->mask.pl, b->w, b->h, b->packed.as<uint8_t>(), per_page, b->n));
+        if (!b->packed.p) {
+            HIP_TRY(hipStreamSynchronize(b->s));
+            TRY(b->packed.alloc(b->ctx, per_page * b->n + 256));
+        }
+        TRY(launch_pack_msb(b->ctx, b->s, b->mask.pl, b->w, b->h, b->packed.as<uint8_t>(), per_page, b->active));
         b->packed_valid = 1;
     }
     HIP_TRY(hipMemcpyAsync(out, b->packed.as<uint8_t>() + per_page * page, (size_t)((b->w + 7) / 8) * b->h,
                            hipMemcpyDeviceToHost, b->s));
-    HIP_TRY(hipStreamSynchronize(b->s));
+    if (wait) HIP_TRY(hipStreamSynchronize(b->s));
     return 0;
+}
+
+MRCHIP_EXPORT int mrchip_batch_download_mask_packed(mrchip_batch *b, int page, uint8_t *out) {
+    return download_mask_packed_impl(b, page, out, true);
+}
+MRCHIP_EXPORT int mrchip_batch_download_mask_packed_async(mrchip_batch *b, int page, uint8_t *out) {
+    return download_mask_packed_impl(b, page, out, false);
+}
+
+// 1 when everything queued on the batch's stream has finished, 0 while work is pending (never blocks)
+MRCHIP_EXPORT int mrchip_batch_done(mrchip_batch *b) {
+    CHECK_B(b);
+    const hipError_t e = hipStreamQuery(b->s);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    set_error("hipStreamQuery: %s", hipGetErrorString(e));
+    return MRCHIP_E_HIP;
 }
 
 static int prepare_thumb(mrchip_batch *b, int Lr, double downsample, int *too_small) {
@@ -511,8 +638,8 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
                       int *too_small_bg) {
     mrchip_ctx *ctx = b->ctx;
     hipStream_t s = b->s;
-    const int w = b->w, h = b->h, c = b->c, N = b->n;
-    const CtrlLayout L(N, (int)b->boxes.size());
+    const int w = b->w, h = b->h, c = b->c, N = b->active;
+    const CtrlLayout L(b->n, b->nb_cap);
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
         if (!b->layer[Lr].pl.p) TRY(b->layer[Lr].alloc(ctx, N, w * c, h));
@@ -628,6 +755,12 @@ MRCHIP_EXPORT mrchip_page *mrchip_page_create(mrchip_ctx *ctx, int w, int h, int
 MRCHIP_EXPORT void mrchip_page_destroy(mrchip_page *pg) { mrchip_batch_destroy(reinterpret_cast<mrchip_batch *>(pg)); }
 MRCHIP_EXPORT int mrchip_page_upload(mrchip_page *pg, const uint8_t *img) {
     return mrchip_batch_upload(reinterpret_cast<mrchip_batch *>(pg), 0, img);
+}
+MRCHIP_EXPORT int mrchip_page_upload_gray(mrchip_page *pg, const uint8_t *gray) {
+    return mrchip_batch_upload_gray(reinterpret_cast<mrchip_batch *>(pg), 0, gray);
+}
+MRCHIP_EXPORT int mrchip_page_upload_mask(mrchip_page *pg, const uint8_t *mask) {
+    return mrchip_batch_upload_mask(reinterpret_cast<mrchip_batch *>(pg), 0, mask);
 }
 MRCHIP_EXPORT int mrchip_page_mask_begin(mrchip_page *pg, const int32_t *boxes, int nb, int window) {
     mrchip_batch *b = reinterpret_cast<mrchip_batch *>(pg);

@@ -16,9 +16,10 @@ using namespace mrchip;
 MRCHIP_EXPORT int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *mismatches) {
     CHECK_CTX(ctx);
     if (!mismatches) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     DevBuf bad;
     TRY(bad.alloc(ctx, 256));
-    hipStream_t s = ctx->streams[0];
     TRY(sauvola_div_selftest(ctx, s, bad.as<unsigned long long>()));
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, s));
@@ -30,9 +31,10 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *
 MRCHIP_EXPORT int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches) {
     CHECK_CTX(ctx);
     if (!mismatches) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     DevBuf bad;
     TRY(bad.alloc(ctx, 256));
-    hipStream_t s = ctx->streams[0];
     TRY(optimise_div_selftest(ctx, s, bad.as<unsigned long long>()));
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, s));
@@ -56,6 +58,7 @@ MRCHIP_EXPORT int mrchip_sauvola_u8(mrchip_ctx *ctx, const uint8_t *in, uint8_t 
     if (!in || !out || w < 0 || h < 0) { set_error("sauvola: bad arguments"); return MRCHIP_E_ARG; }
     if (w == 0 || h == 0) return 0;
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 src, dst;
     TRY(src.alloc(ctx, w, h));
     TRY(dst.alloc(ctx, w, h));
@@ -72,6 +75,7 @@ MRCHIP_EXPORT int mrchip_luma601(mrchip_ctx *ctx, const uint8_t *rgb, uint8_t *g
     if (!rgb || !gray || w < 0 || h < 0) { set_error("luma601: bad arguments"); return MRCHIP_E_ARG; }
     if (w == 0 || h == 0) return 0;
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 src, dst;
     TRY(src.alloc(ctx, w, h, 3));
     TRY(dst.alloc(ctx, w, h));
@@ -89,6 +93,7 @@ MRCHIP_EXPORT int mrchip_mask_denoise(mrchip_ctx *ctx, uint8_t *mask, int w, int
     if (!mask || w < 0 || h < 0) { set_error("mask_denoise: bad arguments"); return MRCHIP_E_ARG; }
     if (w == 0 || h == 0) return 0;
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 m;
     DevBuf bits;
     TRY(m.alloc(ctx, w, h));
@@ -109,6 +114,7 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     if (channels != 1 && channels != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
     if (w == 0 || h == 0) return 0;
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 m, i, o;
     DevBuf jb;
     TRY(m.alloc(ctx, w, h));
@@ -134,6 +140,7 @@ MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int
         return MRCHIP_E_ARG;
     }
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 m;
     DevBuf scratch, res;
     TRY(m.alloc(ctx, w, h));
@@ -173,6 +180,7 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
         return MRCHIP_E_ARG;
     }
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 a, b;
     DevBuf tmp;
     const int tp = round_up(w, 16);
@@ -219,6 +227,7 @@ MRCHIP_EXPORT int mrchip_thumbnail_ex(mrchip_ctx *ctx, const uint8_t *in, int w,
     TRY(ThumbPlan_build(p, w, h, channels, req_w, req_h, filter, reducing_gap));
     if (!p.changed) { memcpy(out, in, (size_t)w * h * channels); return 0; }
     hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     Img8 src;
     DevBuf dst, s1, s2, tab;
     const int c = channels;

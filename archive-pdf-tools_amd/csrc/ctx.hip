@@ -1,6 +1,8 @@
 // Context, caching device allocator, staging copies and HIP-event profiling.
 #include <cstdarg>
 
+#include <algorithm>
+
 #include "mrchip_internal.h"
 
 namespace mrchip {
@@ -15,7 +17,7 @@ void set_error(const char *fmt, ...) {
 }
 
 int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
-    bytes = (bytes + 4095) & ~(size_t)4095;
+    bytes = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;     // never a zero-byte (null) block
     int best = -1;
     for (size_t i = 0; i < ctx->blocks.size(); i++) {
         DevBlock &b = ctx->blocks[i];
@@ -251,13 +253,18 @@ MRCHIP_EXPORT int mrchip_hbm_copy_bandwidth(mrchip_ctx *ctx, size_t bytes, int r
     if (!ctx) { set_error("null context"); return MRCHIP_E_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     if (!gbps || bytes < 4096 || reps < 1) { set_error("hbm_copy_bandwidth: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
     DevBuf a, b;
     TRY(a.alloc(ctx, bytes));
     TRY(b.alloc(ctx, bytes));
-    hipStream_t s = ctx->streams[0];
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    struct Ev {          // destroyed on every path
+        hipEvent_t e = nullptr;
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    } ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0.e));
+    HIP_TRY(hipEventCreate(&ev1.e));
+    hipEvent_t e0 = ev0.e, e1 = ev1.e;
     HIP_TRY(hipMemsetAsync(a.p, 1, bytes, s));
     HIP_TRY(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, s));      // warm-up
     HIP_TRY(hipEventRecord(e0, s));
@@ -266,8 +273,6 @@ MRCHIP_EXPORT int mrchip_hbm_copy_bandwidth(mrchip_ctx *ctx, size_t bytes, int r
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *gbps = ms > 0 ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
     return 0;
 }

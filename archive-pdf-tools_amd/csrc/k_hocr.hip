@@ -6,8 +6,8 @@
 
 namespace mrchip {
 
-__global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, int or_mode) {
-    const int b = blockIdx.z;
+__global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, int first, int or_mode) {
+    const int b = first + blockIdx.z;
     const HocrBox B = boxes[b];
     if (B.decision == 0) return;
     uint8_t *mask = B.mask;
@@ -64,9 +64,13 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
                        int or_mode) {
     if (nb <= 0) return 0;
-    dim3 grid(cdiv(cdiv(maxw + 3, 16), 256), std::min(maxh, 64), nb);
-    LAUNCH(ctx, s, "hocr_commit", (or_mode ? 3.0 : 2.0) * area,
-           hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes, or_mode));
+    // grid.z is limited to 65535: big batches of small pages can hold more boxes than that
+    for (int first = 0; first < nb; first += MAX_GRID_Z) {
+        const int cnt = std::min(MAX_GRID_Z, nb - first);
+        dim3 grid(cdiv(cdiv(maxw + 3, 16), 256), std::min(maxh, 64), cnt);
+        LAUNCH(ctx, s, "hocr_commit", (or_mode ? 3.0 : 2.0) * area * cnt / nb,
+               hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes, first, or_mode));
+    }
     return 0;
 }
 

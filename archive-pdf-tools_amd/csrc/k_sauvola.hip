@@ -19,6 +19,7 @@
 // Traffic per pixel: 1 B written + 1 B read x (strip-halo overlap CW/(CW-ww)) x (tile warm-up
 // (th+wh)/th) x 3 (entering, centre and leaving use of a row; the two re-reads are 25 rows old and
 // come back from L2 / Infinity Cache).  Algorithmic bytes: 2*w*h.
+#include <algorithm>
 #include <cstdlib>
 
 #include "mrchip_internal.h"
@@ -404,6 +405,11 @@ int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_b
 int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, const SauvolaJob *d_jobs,
                        int njobs, int ww, int wh, double k, double R, int flags) {
     if (njobs <= 0) return 0;
+    if (njobs > MAX_GRID_Z) {        // one job per grid.z slice: big batches of small pages go in several launches
+        for (int o = 0; o < njobs; o += MAX_GRID_Z)
+            TRY(launch_sauvola_dev(ctx, s, jobs + o, d_jobs + o, std::min(MAX_GRID_Z, njobs - o), ww, wh, k, R, flags));
+        return 0;
+    }
     if (ww < 1 || wh < 1) { set_error("sauvola: window must be >= 1"); return MRCHIP_E_ARG; }
     if ((long long)ww * wh > 65792) {
         // S = sum of a window < 2^24 (24-bit multiplies, exact fp32) and Q < 2^32

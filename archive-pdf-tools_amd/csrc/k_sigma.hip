@@ -327,6 +327,11 @@ size_t sigma_scratch_bytes(int w, int h, int kind) {
 int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
                                int kind, double *d_sigma) {
     if (njobs <= 0) return 0;
+    if (njobs > MAX_GRID_Z) {        // job index = grid.y / grid.z slice
+        for (int o = 0; o < njobs; o += MAX_GRID_Z)
+            TRY(launch_estimate_sigma_jobs(ctx, s, h_jobs + o, d_jobs + o, std::min(MAX_GRID_Z, njobs - o), kind, d_sigma + o));
+        return 0;
+    }
     for (int i = 0; i < njobs; i++)
         if (h_jobs[i].w <= 0 || h_jobs[i].h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
     if (kind == 0) return run_sigma<float>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);

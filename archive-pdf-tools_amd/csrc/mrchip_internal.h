@@ -74,6 +74,7 @@ struct ProfPending {
 };
 
 constexpr int NSTREAMS = 4;
+constexpr int MAX_GRID_Z = 65535;      // hipDeviceProp_t::maxGridSize[2] (and [1])
 
 }  // namespace mrchip
 
@@ -90,6 +91,9 @@ struct mrchip_ctx {
     std::vector<mrchip::ProfEntry> prof_entries;
     std::vector<mrchip::ProfPending> prof_pending;
     std::vector<hipEvent_t> event_pool;
+    // while an entry point that enqueues asynchronous work on scratch buffers is running: the stream
+    // its DevBufs must wait for before they go back to the allocator (error paths return early)
+    hipStream_t scratch_sync = nullptr;
     int cus = 0;
     size_t hbm = 0;
     char name[128] = {};
@@ -114,11 +118,26 @@ struct DevBuf {   // RAII for scratch inside an entry point
         return dev_alloc(c, bytes, &p);
     }
     void release() {
-        if (p) dev_free(ctx, p);
+        if (p) {
+            // an early (error) return may leave kernels / copies in flight on the entry point's stream
+            if (ctx->scratch_sync) (void)hipStreamSynchronize(ctx->scratch_sync);
+            dev_free(ctx, p);
+        }
         p = nullptr;
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Declared first in a host-buffer entry point: every scratch DevBuf released while it is alive waits for
+// `s` (free on the success path, where the stream is already idle).
+struct ScratchSync {
+    mrchip_ctx *ctx;
+    hipStream_t prev;
+    ScratchSync(mrchip_ctx *c, hipStream_t s) : ctx(c), prev(c->scratch_sync) { c->scratch_sync = s; }
+    ~ScratchSync() { ctx->scratch_sync = prev; }
+    ScratchSync(const ScratchSync &) = delete;
+    ScratchSync &operator=(const ScratchSync &) = delete;
 };
 
 // pitched 8-bit image (c interleaved channels per pixel)

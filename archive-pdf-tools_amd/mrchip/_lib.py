@@ -64,8 +64,14 @@ SIGNATURES = {
     'mrchip_batch_create': (vp, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     'mrchip_batch_destroy': (None, [vp]),
     'mrchip_batch_upload': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_upload_gray': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_upload_mask': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_page_upload_gray': (C.c_int, [vp, u8p]),
+    'mrchip_page_upload_mask': (C.c_int, [vp, u8p]),
+    'mrchip_batch_set_count': (C.c_int, [vp, C.c_int]),
     'mrchip_batch_set_boxes': (C.c_int, [vp, C.c_int, i32p, C.c_int]),
     'mrchip_batch_mask_begin': (C.c_int, [vp, C.c_int]),
+    'mrchip_batch_threshold': (C.c_int, [vp, C.c_int, C.c_double]),
     'mrchip_batch_sigmas': (C.c_int, [vp, f64p]),
     'mrchip_batch_mask_finish': (C.c_int, [vp, f64p, intp, C.c_int]),
     'mrchip_batch_download_mask': (C.c_int, [vp, C.c_int, u8p]),
@@ -73,6 +79,9 @@ SIGNATURES = {
     'mrchip_batch_layers': (C.c_int, [vp, C.c_int, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
     'mrchip_batch_download_layer': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
     'mrchip_batch_download_layer_async': (C.c_int, [vp, C.c_int, C.c_int, u8p]),
+    'mrchip_batch_download_mask_async': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_download_mask_packed_async': (C.c_int, [vp, C.c_int, u8p]),
+    'mrchip_batch_done': (C.c_int, [vp]),
     'mrchip_host_alloc': (C.c_void_p, [vp, C.c_size_t]),
     'mrchip_host_free': (None, [vp, C.c_void_p]),
     'mrchip_batch_sync': (C.c_int, [vp]),
@@ -163,7 +172,12 @@ class Context:
             raise MrchipError('mrchip_host_alloc(%d) failed: %s' % (nbytes, last_error()))
         buf = (C.c_ubyte * max(nbytes, 1)).from_address(p)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        weakref.finalize(buf, lib.mrchip_host_free, None, p)      # hipHostFree needs no particular device
+        _PINNED[p] = max(nbytes, 1)
+
+        def _release(addr=p):
+            _PINNED.pop(addr, None)
+            lib.mrchip_host_free(None, addr)      # hipHostFree needs no particular device
+        weakref.finalize(buf, _release)
         return arr
 
     def hbm_copy_bandwidth(self, nbytes=1 << 30, reps=10):
@@ -192,6 +206,20 @@ class Context:
             check(lib.mrchip_prof_get(self.handle, i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
             out[name.value.decode()] = {'launches': launches.value, 'ms': ms.value, 'alg_bytes': ab.value}
         return out
+
+
+_PINNED = {}        # address -> bytes of the live pinned_empty allocations
+
+
+def is_pinned(arr):
+    """True when `arr`'s bytes lie inside a Context.pinned_empty allocation: copies from / to it are true
+    asynchronous DMAs, anything else makes the HIP runtime stage the copy and block the calling thread."""
+    a = arr.ctypes.data
+    n = arr.nbytes
+    for base, size in _PINNED.items():
+        if base <= a and a + n <= base + size:
+            return True
+    return False
 
 
 _tls = threading.local()

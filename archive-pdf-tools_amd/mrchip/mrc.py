@@ -46,6 +46,18 @@ def threshold_image(img, dpi, k=0.34, ctx=None):
     return out_img.view(np.bool_)
 
 
+def _u8_valued(imgf, what):
+    """The float32 images of this path are `np.array(grayimg, dtype=np.float32)` (mrc.py:372): whole numbers
+    0..255.  The device works on the uint8 plane; anything else is refused, never approximated."""
+    a = np.asarray(imgf)
+    if a.ndim != 2:
+        raise ValueError('%s: a 2-D image is expected, got shape %r' % (what, a.shape))
+    src = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.dtype != np.uint8 and not np.array_equal(src, a):
+        raise _lib.MrchipError('%s: only images holding uint8 values (0..255, whole numbers) are supported' % what)
+    return src
+
+
 def mean_estimate_sigma(arr, ctx=None):
     """mrc.mean_estimate_sigma (mrc.py:52-55) for float32 images holding uint8 values or bool arrays."""
     a = np.asarray(arr)
@@ -67,8 +79,7 @@ def mean_estimate_sigma(arr, ctx=None):
 
 def estimate_noise(imgf, ctx=None):
     """mrc.estimate_noise (mrc.py:273-296) on float32(gray)."""
-    a = np.asarray(imgf)
-    src = np.ascontiguousarray(a, dtype=np.uint8)
+    src = _u8_valued(imgf, 'estimate_noise')
     h, w = src.shape
     ctx = ctx or _lib.default_context()
     sigma = C.c_double()
@@ -90,39 +101,39 @@ def gaussian_weights(sigma):
     return np.ascontiguousarray(phi_x[::-1], dtype=np.float64), lw
 
 
+def _line_box(line, scale):
+    """One hOCR line -> (left, top, right, bottom) in page pixels, or None when create_hocr_mask skips the
+    line without a message (mrc.py:198-213): no text, mean word confidence under 20, or an empty box."""
+    words = line['words']
+    if not ' '.join(w['text'] for w in words).strip():
+        return None
+    conf = [w['confidence'] for w in words]
+    if (sum(conf) / len(conf) if conf else 0) < 20:
+        return None
+    box = tuple(int(v / scale) if scale is not None else int(v) for v in line['bbox'])
+    if box[0] == box[2] or box[1] == box[3]:
+        return None
+    return box
+
+
 def hocr_boxes(hocr_word_data, image_width, image_height, downsample=None):
-    """Text / confidence / geometry filter of mrc.create_hocr_mask (mrc.py:194-221): host logic."""
-    boxes = []
+    """The line filter of mrc.create_hocr_mask (mrc.py:194-221) as host logic: int32[nb,4] boxes in list
+    order.  Inverted boxes and boxes that leave the page are reported on stderr with the reference's
+    messages (mrc.py:216, 220) and dropped."""
+    kept = []
     for paragraph in hocr_word_data:
         for line in paragraph['lines']:
-            coords = line['bbox']
-
-            line_text = ' '.join([word['text'] for word in line['words']])
-            line_confs = [word['confidence'] for word in line['words']]
-            line_conf = sum(line_confs) / len(line_confs) if len(line_confs) else 0
-
-            if line_text.strip() == '' or line_conf < 20:
+            box = _line_box(line, downsample)
+            if box is None:
                 continue
-
-            if downsample is not None:
-                coords = [int(x / downsample) for x in coords]
+            l, t, r, b = box
+            if l >= r or t >= b:
+                print('Invalid bounding box: (%d, %d, %d, %d)' % box, file=sys.stderr)
+            elif l < 0 or t < 0 or r > image_width or b > image_height:
+                print('Invalid bounding box outside image: (%d, %d, %d, %d)' % box, file=sys.stderr)
             else:
-                coords = [int(x) for x in coords]
-
-            left, top, right, bottom = coords
-            if left == right or top == bottom:
-                continue
-
-            if (left >= right) or (top >= bottom):
-                print('Invalid bounding box: (%d, %d, %d, %d)' % (left, top, right, bottom), file=sys.stderr)
-                continue
-
-            if (left < 0) or (right > image_width) or (top < 0) or (bottom > image_height):
-                print('Invalid bounding box outside image: (%d, %d, %d, %d)' % (left, top, right, bottom),
-                      file=sys.stderr)
-                continue
-            boxes.append((left, top, right, bottom))
-    return np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+                kept.append(box)
+    return np.ascontiguousarray(np.asarray(kept, dtype=np.int32).reshape(-1, 4))
 
 
 def create_hocr_mask(img, mask_arr, hocr_word_data, downsample=None, dpi=None, timing_data=None, ctx=None):
@@ -131,8 +142,10 @@ def create_hocr_mask(img, mask_arr, hocr_word_data, downsample=None, dpi=None, t
     image_height, image_width = np_img.shape
     t = time()
     boxes = hocr_boxes(hocr_word_data, image_width, image_height, downsample)
+    m = np.asarray(mask_arr)
+    if m.shape != np_img.shape:
+        raise ValueError('create_hocr_mask: mask_arr shape %r does not match the image %r' % (m.shape, np_img.shape))
     if len(boxes):
-        m = np.asarray(mask_arr)
         tmp = _lib.as_u8(m, 'mask_arr')
         ctx = ctx or _lib.default_context()
         _lib.check(_lib.load().mrchip_hocr_mask(ctx.handle, _lib.ptr(np_img), _lib.ptr(tmp), image_width, image_height,
@@ -142,6 +155,65 @@ def create_hocr_mask(img, mask_arr, hocr_word_data, downsample=None, dpi=None, t
             m[...] = tmp.view(m.dtype) if m.dtype == np.bool_ else tmp
     if timing_data is not None:
         timing_data.append(('hocr_mask_gen', time() - t))
+
+
+def create_threshold_mask(mask_arr, imgf, dpi=None, denoise_mask=None, timing_data=None, ctx=None):
+    """mrc.create_threshold_mask (mrc.py:300-329): noise estimate, Gaussian blur when sigma_est > 1, Sauvola
+    k=0.34 of the (truncated) result, OR-ed into mask_arr in place.  `imgf` is float32(gray) as in
+    mrc.py:372; `denoise_mask` is accepted and unused like in the reference.  Timing keys est_1 / blur_1 /
+    threshold as the reference appends them."""
+    gray = _u8_valued(imgf, 'create_threshold_mask')
+    m = np.asarray(mask_arr)
+    if m.shape != gray.shape:
+        raise ValueError('create_threshold_mask: mask_arr shape %r does not match the image %r' % (m.shape, gray.shape))
+    ctx = ctx or _lib.default_context()
+    t = time()
+    sigma_est = estimate_noise(gray, ctx=ctx)
+    if timing_data is not None:
+        timing_data.append(('est_1', time() - t))
+    if sigma_est > 1.0:                                                   # mrc.py:309-313
+        t = time()
+        wts, radius = gaussian_weights(sigma_est * 0.1)
+        h, w = gray.shape
+        blurred = np.empty_like(gray)
+        _lib.check(_lib.load().mrchip_gaussian_u8(ctx.handle, _lib.ptr(gray), _lib.ptr(blurred), w, h,
+                                                  float(sigma_est * 0.1), _lib.ptr(wts, _lib.f64p), radius),
+                   'mrchip_gaussian_u8')
+        gray = blurred                                                    # imgf.astype(np.uint8), mrc.py:325
+        if timing_data is not None:
+            timing_data.append(('blur_1', time() - t))
+    t = time()
+    thres_arr = threshold_image(gray, dpi, ctx=ctx)
+    if timing_data is not None:
+        timing_data.append(('threshold', time() - t))
+    if m.dtype == np.bool_:
+        m |= thres_arr                                                    # mrc.py:329
+    else:
+        m |= thres_arr.view(np.uint8)
+
+
+def denoise_bregman(binary_img):
+    """mrc.denoise_bregman (mrc.py:90-108): host passthrough to scikit-image's iterative TV solver, which is
+    third-party code the reference calls as is (SURVEY.md 8f rank 4 keeps it on the CPU).  Raises
+    ImportError where scikit-image is not installed -- there is no stand-in."""
+    try:
+        from skimage.restoration import denoise_tv_bregman
+    except ImportError as e:
+        raise ImportError("denoise_mask='bregman' needs scikit-image (skimage.restoration.denoise_tv_bregman), "
+                          "the same dependency the reference uses for it (mrc.py:34, 101)") from e
+    thresf = np.array(binary_img, dtype=np.float32)
+    return np.array(denoise_tv_bregman(thresf, weight=1.) > 0.4, dtype=bool)
+
+
+def _checked_page(arr, w, h, c, what):
+    """C-contiguous uint8 array of exactly the handle's geometry: the library copies w*c*h bytes from the
+    pointer, so a smaller or differently shaped array must be refused here (ValueError like a Cython buffer
+    mismatch in the reference)."""
+    a = _lib.as_u8(arr, what)
+    want = (h, w) if c == 1 else (h, w, c)
+    if a.shape != want:
+        raise ValueError('%s: array of shape %r expected, got %r' % (what, want, a.shape))
+    return a
 
 
 class _Page:
@@ -167,7 +239,16 @@ class _Page:
             pass
 
     def upload(self, arr):
+        arr = _checked_page(arr, self.w, self.h, self.c, 'page')
         _lib.check(self.lib.mrchip_page_upload(self._h, _lib.ptr(arr)), 'mrchip_page_upload')
+
+    def upload_gray(self, gray):
+        gray = _checked_page(gray, self.w, self.h, 1, 'gray plane')
+        _lib.check(self.lib.mrchip_page_upload_gray(self._h, _lib.ptr(gray)), 'mrchip_page_upload_gray')
+
+    def upload_mask(self, mask):
+        mask = _checked_page(mask, self.w, self.h, 1, 'mask')
+        _lib.check(self.lib.mrchip_page_upload_mask(self._h, _lib.ptr(mask)), 'mrchip_page_upload_mask')
 
     def mask_begin(self, boxes, window):
         _lib.check(self.lib.mrchip_page_mask_begin(self._h, _lib.ptr(boxes, _lib.i32p) if len(boxes) else None,
@@ -238,8 +319,21 @@ class Batch:
             pass
 
     def upload(self, page, arr):
-        arr = _lib.as_u8(arr)
+        arr = _checked_page(arr, self.w, self.h, self.c, 'page')
         _lib.check(self.lib.mrchip_batch_upload(self._h, page, _lib.ptr(arr)), 'mrchip_batch_upload')
+
+    def upload_gray(self, page, gray):
+        """Gray plane of an RGB page from the caller (PIL's convert('L') of a mode other than L / RGB)."""
+        gray = _checked_page(gray, self.w, self.h, 1, 'gray plane')
+        _lib.check(self.lib.mrchip_batch_upload_gray(self._h, page, _lib.ptr(gray)), 'mrchip_batch_upload_gray')
+
+    def upload_mask(self, page, mask):
+        mask = _checked_page(mask, self.w, self.h, 1, 'mask')
+        _lib.check(self.lib.mrchip_batch_upload_mask(self._h, page, _lib.ptr(mask)), 'mrchip_batch_upload_mask')
+
+    def set_count(self, count):
+        """Pages in use (1..n): the stages then skip pages >= count (a short last batch of a stream)."""
+        _lib.check(self.lib.mrchip_batch_set_count(self._h, count), 'mrchip_batch_set_count')
 
     def set_boxes(self, page, boxes):
         boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
@@ -248,6 +342,10 @@ class Batch:
 
     def mask_begin(self, window):
         _lib.check(self.lib.mrchip_batch_mask_begin(self._h, window), 'mrchip_batch_mask_begin')
+
+    def threshold(self, dpi=None, k=0.34):
+        """mrc.threshold_image (mrc.py:58-87) of every page in one launch; the result is the batch's mask."""
+        _lib.check(self.lib.mrchip_batch_threshold(self._h, _window_size(dpi), float(k)), 'mrchip_batch_threshold')
 
     def sigmas(self):
         s = np.zeros(self.n, dtype=np.float64)
@@ -274,19 +372,36 @@ class Batch:
                    'mrchip_batch_layers')
         return (fw.value, fh.value), (bw.value, bh.value), ts.value
 
-    def download_mask(self, page):
-        m = np.empty((self.h, self.w), dtype=np.uint8)
-        _lib.check(self.lib.mrchip_batch_download_mask(self._h, page, _lib.ptr(m)), 'mrchip_batch_download_mask')
+    @staticmethod
+    def _dest(out, shape, what):
+        if out is None:
+            return np.empty(shape, dtype=np.uint8)
+        if out.shape != shape or out.dtype not in (np.uint8, np.bool_) or not out.flags.c_contiguous:
+            raise ValueError('%s: out must be a C-contiguous 1-byte array of shape %r' % (what, shape))
+        return out
+
+    def download_mask(self, page, out=None, wait=True):
+        """bool[h,w] mask of one page; out / wait as in download_layer."""
+        m = self._dest(out, (self.h, self.w), 'download_mask')
+        fn = self.lib.mrchip_batch_download_mask if wait else self.lib.mrchip_batch_download_mask_async
+        _lib.check(fn(self._h, page, _lib.ptr(m.view(np.uint8))), 'mrchip_batch_download_mask')
         return m.view(np.bool_)
 
-    def download_mask_packed(self, page):
+    def download_mask_packed(self, page, out=None, wait=True):
         """The finished mask at 1 bit per pixel (MSB first, rows of ceil(w/8) bytes): what
         mrc.encode_mrc_mask (mrc.py:474-520) feeds to jbig2 / PNG, an eighth of the bytes over PCIe.
         `PIL.Image.frombytes('1', (w, h), packed.tobytes())` equals `Image.fromarray(mask)`."""
-        out = np.empty((self.h, (self.w + 7) // 8), dtype=np.uint8)
-        _lib.check(self.lib.mrchip_batch_download_mask_packed(self._h, page, _lib.ptr(out)),
-                   'mrchip_batch_download_mask_packed')
-        return out
+        m = self._dest(out, (self.h, (self.w + 7) // 8), 'download_mask_packed')
+        fn = self.lib.mrchip_batch_download_mask_packed if wait else self.lib.mrchip_batch_download_mask_packed_async
+        _lib.check(fn(self._h, page, _lib.ptr(m)), 'mrchip_batch_download_mask_packed')
+        return m
+
+    def done(self):
+        """True when nothing is pending on the batch's stream (never blocks)."""
+        rc = self.lib.mrchip_batch_done(self._h)
+        if rc < 0:
+            _lib.check(rc, 'mrchip_batch_done')
+        return bool(rc)
 
     def download_layer(self, page, is_bg, size, out=None, wait=True):
         """fg (is_bg=0) / bg layer of one page.  `out`: destination array (e.g. Context.pinned_empty); with
@@ -311,55 +426,189 @@ class Batch:
         _lib.check(self.lib.mrchip_batch_sync(self._h), 'mrchip_batch_sync')
 
 
-def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
-                    denoise_mask=DENOISE_FAST, ctx=None, max_batch_bytes=64 << 30):
-    """Batch form of create_mrc_hocr_components: returns a list of (mask, fg, bg) tuples equal to what the
-    generator yields page by page, in input order.  Pages are grouped by (width, height, mode) -- a device
-    batch holds pages of one size -- and each group is cut into batches of at most `max_batch_bytes` of
-    device memory."""
-    arrs = [_image_to_array(im) for im in images]
-    if len(arrs) != len(hocr_list):
-        raise ValueError('decompose_pages: one hOCR page per image expected')
+class _StreamJob:
+    """One device batch travelling through decompose_stream: fill (upload + phase A), mid (phase B + layers +
+    queued downloads), drain (wait, hand out the arrays)."""
+
+    def __init__(self, slot, items):
+        self.slot = slot            # _StreamSlot
+        self.items = items          # [(pixels, gray, hocr)]
+        self.sizes = None
+
+
+class _StreamSlot:
+    """A Batch plus the pinned host arrays its results are copied into; reused batch after batch."""
+
+    def __init__(self, ctx, n, w, h, c):
+        self.batch = Batch(ctx, n, w, h, c)
+        self.ctx = ctx
+        self.key = (n, w, h, c)
+        self.out = {}               # name -> pinned array [n, ...]
+
+    def pinned(self, name, shape):
+        a = self.out.get(name)
+        if a is None or a.shape != shape:
+            a = self.ctx.pinned_empty(shape)
+            self.out[name] = a
+        return a
+
+    def close(self):
+        self.batch.close()
+        self.out.clear()
+
+
+def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
+                     denoise_mask=DENOISE_FAST, ctx=None, batch_pages=32, slots=3, mask_format='bool', copy=False):
+    """The page loop of recode.py:291-492 as a pipeline: `pages` is an iterable of (image, hocr_word_data);
+    yields (mask, fg, bg) per page, in input order, equal to what create_mrc_hocr_components yields for it.
+
+    Consecutive pages of one size and mode are collected into device batches of up to `batch_pages`; `slots`
+    (>= 3) batches rotate, each on its own HIP stream: while batch i is being decomposed, batch i+1 crosses
+    PCIe to the device and the results of batch i-1 cross back into page-locked host arrays (enqueue-only
+    copies), so both directions of the link and the GPU are busy at once.  Images that live in
+    Context.pinned_empty arrays are uploaded by asynchronous DMA; any other array makes the HIP runtime
+    stage the copy while this thread waits (the downloads and the kernels of the other batches still overlap).
+
+    mask_format: 'bool' -- bool[h,w] like the reference's first yield; 'packed' -- uint8[h,(w+7)//8], 1 bit per
+    pixel MSB first (PIL mode '1' / PBM rows, what mrc.encode_mrc_mask builds for jbig2; an eighth of the bytes).
+    copy=False hands out views of the pinned result arrays, valid until `batch_pages` further pages have been
+    taken from the generator; copy=True returns arrays the caller owns."""
     if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
-        raise ValueError('Invalid denoise option:', denoise_mask)
+        raise ValueError('Invalid denoise option:', denoise_mask)     # bregman is a host pass: use the generator
+    if mask_format not in ('bool', 'packed'):
+        raise ValueError("mask_format must be 'bool' or 'packed'")
+    if slots < 3 or batch_pages < 1:
+        raise ValueError('decompose_stream: slots >= 3 and batch_pages >= 1 expected')
     ctx = ctx or _lib.default_context()
-    groups = {}
-    for i, a in enumerate(arrs):
-        groups.setdefault((a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3), []).append(i)
-    out = [None] * len(arrs)
-    for (h, w, c), idx in groups.items():
-        per_page = w * h * (10 + 6 * c) + (4 << 20)          # planes of a page in a batch (DESIGN.md 2)
-        step = max(1, int(max_batch_bytes // per_page))
-        for k in range(0, len(idx), step):
-            part = idx[k:k + step]
-            b = Batch(ctx, len(part), w, h, c)
-            try:
-                for j, i in enumerate(part):
-                    b.upload(j, arrs[i])
-                    b.set_boxes(j, hocr_boxes(hocr_list[i], w, h, downsample))
-                b.mask_begin(_window_size(dpi))
-                b.mask_finish(b.sigmas(), denoise_mask == DENOISE_FAST)
-                fgs, bgs, _ = b.layers(fg_downsample, bg_downsample)
-                for j, i in enumerate(part):
-                    out[i] = (b.download_mask(j), b.download_layer(j, 0, fgs), b.download_layer(j, 1, bgs))
-            finally:
-                b.close()
+    window = _window_size(dpi)
+    free = {}                  # (n, w, h, c) -> [idle _StreamSlot]
+    every = []
+
+    def take_slot(n, w, h, c):
+        pool = free.setdefault((n, w, h, c), [])
+        if pool:
+            return pool.pop()
+        sl = _StreamSlot(ctx, n, w, h, c)
+        every.append(sl)
+        return sl
+
+    def fill(items):
+        h, w = items[0][0].shape[:2]
+        c = 1 if items[0][0].ndim == 2 else 3
+        job = _StreamJob(take_slot(batch_pages, w, h, c), items)
+        bt = job.slot.batch
+        for j, (arr, gray, hocr) in enumerate(items):
+            bt.upload(j, arr)
+            if gray is not None:
+                bt.upload_gray(j, gray)
+            bt.set_boxes(j, hocr_boxes(hocr, w, h, downsample))
+        bt.set_count(len(items))                     # a short last batch leaves the other pages untouched
+        bt.mask_begin(window)
+        return job
+
+    def mid(job):
+        bt = job.slot.batch
+        n, w, h, c = job.slot.key
+        bt.mask_finish(bt.sigmas(), denoise_mask == DENOISE_FAST)
+        fgs, bgs, _ = bt.layers(fg_downsample, bg_downsample)
+        job.sizes = (fgs, bgs)
+        mshape = (n, h, (w + 7) // 8) if mask_format == 'packed' else (n, h, w)
+        m = job.slot.pinned('mask', mshape)
+        fg = job.slot.pinned('fg', (n, fgs[1], fgs[0]) + ((3,) if c == 3 else ()))
+        bg = job.slot.pinned('bg', (n, bgs[1], bgs[0]) + ((3,) if c == 3 else ()))
+        for j in range(len(job.items)):
+            if mask_format == 'packed':
+                bt.download_mask_packed(j, out=m[j], wait=False)
+            else:
+                bt.download_mask(j, out=m[j], wait=False)
+            bt.download_layer(j, 0, fgs, out=fg[j], wait=False)
+            bt.download_layer(j, 1, bgs, out=bg[j], wait=False)
+
+    def drain(job):
+        bt = job.slot.batch
+        bt.sync()
+        m, fg, bg = job.slot.out['mask'], job.slot.out['fg'], job.slot.out['bg']
+        for j in range(len(job.items)):
+            mj = m[j] if mask_format == 'packed' else m[j].view(np.bool_)
+            if copy:
+                yield mj.copy(), fg[j].copy(), bg[j].copy()
+            else:
+                yield mj, fg[j], bg[j]
+        job.items = None
+        free[job.slot.key].append(job.slot)
+
+    inflight = []                # jobs in pipeline order; [-1] filled, [-2] ready for mid, [0] drains next
+
+    def advance(job):
+        inflight.append(job)
+        if len(inflight) >= 2 and inflight[-2].sizes is None:
+            mid(inflight[-2])
+        if len(inflight) >= slots:
+            yield from drain(inflight.pop(0))
+
+    try:
+        run, key = [], None
+        for image, hocr in pages:
+            arr, gray = _image_to_array(image)
+            k = (arr.shape[0], arr.shape[1], arr.ndim)
+            if run and (k != key or len(run) == batch_pages):
+                yield from advance(fill(run))
+                run = []
+            key = k
+            run.append((arr, gray, hocr))
+        if run:
+            yield from advance(fill(run))
+        for job in inflight:
+            if job.sizes is None:
+                mid(job)
+        while inflight:
+            yield from drain(inflight.pop(0))
+    finally:
+        for sl in every:
+            sl.close()
+
+
+def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
+                    denoise_mask=DENOISE_FAST, ctx=None, batch_pages=32, max_batch_bytes=None):
+    """Batch form of create_mrc_hocr_components: the list of (mask, fg, bg) tuples the generator would yield
+    page by page, in input order (arrays owned by the caller).  Pages of different sizes / modes may be mixed:
+    consecutive pages of one geometry share a device batch (decompose_stream does the work)."""
+    images = list(images)
+    hocr_list = list(hocr_list)
+    if len(images) != len(hocr_list):
+        raise ValueError('decompose_pages: one hOCR page per image expected')
+    # pages grouped by geometry so that every device batch is as full as it can be; results go back in input order
+    geo = [np.asarray(im).shape if not hasattr(im, 'mode') else (im.size[1], im.size[0], im.mode) for im in images]
+    order = sorted(range(len(images)), key=lambda i: (str(geo[i]), i))
+    out = [None] * len(images)
+    if max_batch_bytes is not None and images:       # cap on the device memory of one batch (DESIGN.md 2)
+        per_page = max(int(g[0]) * int(g[1]) * 28 + (4 << 20) for g in geo)
+        batch_pages = max(1, min(batch_pages, int(max_batch_bytes // per_page)))
+    gen = decompose_stream(((images[i], hocr_list[i]) for i in order), dpi=dpi, downsample=downsample,
+                           bg_downsample=bg_downsample, fg_downsample=fg_downsample, denoise_mask=denoise_mask,
+                           ctx=ctx, batch_pages=max(1, min(batch_pages, len(images))), copy=True)
+    for i, res in zip(order, gen):
+        out[i] = res
     return out
 
 
 def _image_to_array(image):
-    """(array uint8 [h,w] or [h,w,3], had_grey_conversion_mode) from a PIL image or ndarray."""
+    """(pixels, gray) from a PIL image or ndarray: pixels uint8 [h,w] or [h,w,3]; gray is None unless the
+    image is a PIL image of a mode other than L / RGB.  For those the reference thresholds
+    `image.convert('L')` of the ORIGINAL image (mrc.py:359-361) and converts to RGB only for the layers
+    (mrc.py:401-404) -- Pillow's L conversion of e.g. YCbCr, CMYK or P is not the luma of the RGB conversion
+    -- so both planes are made on the host by Pillow's own mode rules and uploaded."""
+    gray = None
     if hasattr(image, 'mode'):
         if image.mode not in ('L', 'RGB'):
-            # mrc.py:401-404 converts other modes to RGB for the layers; convert('L') of such an
-            # image (mrc.py:361) goes through Pillow's own mode rules and is not on the GPU path
+            gray = np.ascontiguousarray(np.array(image.convert('L')))
             image = image.convert('RGB')
         arr = np.array(image)
     else:
         arr = np.asarray(image)
     if arr.dtype != np.uint8 or arr.ndim not in (2, 3) or (arr.ndim == 3 and arr.shape[2] != 3):
         raise ValueError('expected an 8-bit L or RGB image, got dtype %s shape %s' % (arr.dtype, arr.shape))
-    return np.ascontiguousarray(arr)
+    return np.ascontiguousarray(arr), gray
 
 
 def create_mrc_hocr_components(image, hocr_word_data,
@@ -371,17 +620,16 @@ def create_mrc_hocr_components(image, hocr_word_data,
                                errors=None, ctx=None):
     """mrc.create_mrc_hocr_components (mrc.py:334-471): generator yielding mask (bool[h,w]),
     foreground and background (uint8 arrays), lazily, with the reference's timing keys."""
-    image_arr = _image_to_array(image)
+    image_arr, gray_arr = _image_to_array(image)
     height_, width_ = image_arr.shape[:2]
     channels = 1 if image_arr.ndim == 2 else 3
-    if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
-        if denoise_mask == DENOISE_BREGMAN:
-            raise NotImplementedError("denoise_mask='bregman' (mrc.py:90-108) is outside the GPU hot path")
     ctx = ctx or _lib.default_context()
     page = _Page(ctx, width_, height_, channels)
     try:
         t = time()
         page.upload(image_arr)
+        if gray_arr is not None:
+            page.upload_gray(gray_arr)
         boxes = hocr_boxes(hocr_word_data, width_, height_, downsample)
         page.mask_begin(boxes, _window_size(dpi))
         sigma_est = page.sigma()
@@ -393,8 +641,6 @@ def create_mrc_hocr_components(image, hocr_word_data,
                 timing_data.append(('grey_conversion', 0.0))
             timing_data.append(('hocr_mask_gen', now - t))
             timing_data.append(('est_1', 0.0))
-        if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
-            raise ValueError('Invalid denoise option:', denoise_mask)         # mrc.py:396
         t = time()
         page.mask_finish(sigma_est, denoise_mask == DENOISE_FAST)
         mask_arr = page.download_mask()
@@ -405,6 +651,14 @@ def create_mrc_hocr_components(image, hocr_word_data,
             timing_data.append(('threshold', now - t))                        # mrc.py:327
             if denoise_mask == DENOISE_FAST:
                 timing_data.append(('fast_denoise', 0.0))                     # mrc.py:390
+        if denoise_mask == DENOISE_BREGMAN:                                   # mrc.py:391-394, on the host
+            t = time()
+            mask_arr = denoise_bregman(mask_arr)
+            page.upload_mask(mask_arr)
+            if timing_data is not None:
+                timing_data.append(('denoise', time() - t))
+        elif denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
+            raise ValueError('Invalid denoise option:', denoise_mask)         # mrc.py:396
         yield mask_arr
 
         for is_bg, ds, key in ((0, fg_downsample, 'fg'), (1, bg_downsample, 'bg')):

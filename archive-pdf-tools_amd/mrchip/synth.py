@@ -163,3 +163,20 @@ def kat_pattern(w, h, channels=1):
     bars = ((y % 40 >= 12) & (y % 40 < 28)) & ((x // 6) % 3 == 0) & (x > w // 10) & (x < w - w // 10)
     px = np.where(bars, v % 64, 160 + v % 90).astype(np.uint8)
     return np.ascontiguousarray(px[:, :, 0] if channels == 1 else px)
+
+
+def synth_pages(specs, threads=None):
+    """[synth_page(**spec) for spec in specs] on a thread pool (numpy releases the GIL in the array work);
+    spec = dict of synth_page's arguments."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if threads is None:
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 32, len(specs)))
+    if threads == 1:
+        return [synth_page(**sp) for sp in specs]
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(lambda sp: synth_page(**sp), specs))

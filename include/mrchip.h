@@ -131,6 +131,9 @@ mrchip_page *mrchip_page_create(mrchip_ctx *ctx, int w, int h, int channels);
 void mrchip_page_destroy(mrchip_page *pg);
 /* uint8[h][w][channels] host image -> device (asynchronous on the page's stream) */
 int mrchip_page_upload(mrchip_page *pg, const uint8_t *img);
+/* see mrchip_batch_upload_gray / mrchip_batch_upload_mask */
+int mrchip_page_upload_gray(mrchip_page *pg, const uint8_t *gray);
+int mrchip_page_upload_mask(mrchip_page *pg, const uint8_t *mask);
 /* Phase A (enqueue only): luma, both hOCR-box thresholds + counts, noise estimate. */
 int mrchip_page_mask_begin(mrchip_page *pg, const int32_t *boxes, int nb, int window);
 /* Waits for phase A; returns sigma_est (mrc.py:305).  The caller (host, like
@@ -166,9 +169,23 @@ int mrchip_page_device_ptrs(mrchip_page *pg, void **img, void **mask, size_t *ma
 mrchip_batch *mrchip_batch_create(mrchip_ctx *ctx, int npages, int w, int h, int channels);
 void mrchip_batch_destroy(mrchip_batch *b);
 int mrchip_batch_upload(mrchip_batch *b, int page, const uint8_t *img);
+/* Gray plane of an RGB page supplied by the caller instead of the Rec.601 luma of its pixels:
+ * create_mrc_hocr_components thresholds `image.convert('L')` of the ORIGINAL image (mrc.py:359-361) and
+ * converts modes other than L / RGB to RGB only for the layers (mrc.py:401-404).  After mrchip_batch_upload. */
+int mrchip_batch_upload_gray(mrchip_batch *b, int page, const uint8_t *gray);
+/* Replace the finished mask of a page (uint8/bool[h][w]) before mrchip_batch_layers: the hook for mask
+ * post-processing kept on the host -- denoise_mask='bregman' (mrc.py:90-108, 391-392). */
+int mrchip_batch_upload_mask(mrchip_batch *b, int page, const uint8_t *mask);
+/* Number of pages in use, 1..npages (default npages): one batch object serves a short last batch of a
+ * stream; pages >= count are neither read nor written by any stage. */
+int mrchip_batch_set_count(mrchip_batch *b, int count);
 /* filtered hOCR line boxes of one page (mrc.py:198-221 is host logic), list order */
 int mrchip_batch_set_boxes(mrchip_batch *b, int page, const int32_t *boxes, int nb);
 int mrchip_batch_mask_begin(mrchip_batch *b, int window);
+/* mrc.threshold_image(gray, dpi, k) (mrc.py:58-87) of every page in one launch (window from
+ * mrchip_window_for_dpi): True = dark into the mask plane, downloaded with mrchip_batch_download_mask*.
+ * Enqueue only. */
+int mrchip_batch_threshold(mrchip_batch *b, int window, double k);
 /* waits for phase A; sigma_est[npages] (mrc.py:305) */
 int mrchip_batch_sigmas(mrchip_batch *b, double *sigma_est);
 /* weights: npages rows of MRCHIP_MAX_TAPS doubles (row i used iff sigma_est[i] > 1),
@@ -186,6 +203,13 @@ int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_bg, uint8_t *o
  * pinned (mrchip_host_alloc) -- so page i can go to its encoder while page i+1 is still on the device.
  * mrchip_batch_sync before the bytes are read. */
 int mrchip_batch_download_layer_async(mrchip_batch *b, int page, int is_bg, uint8_t *out);
+/* the same for the mask (bool bytes / 1 bpp): what a streaming caller queues behind mrchip_batch_layers so
+ * that batch i-1 leaves over PCIe while batch i is computed and batch i+1 arrives (recode.py:291's page
+ * loop, pipelined) */
+int mrchip_batch_download_mask_async(mrchip_batch *b, int page, uint8_t *mask);
+int mrchip_batch_download_mask_packed_async(mrchip_batch *b, int page, uint8_t *packed);
+/* 1 when everything queued on the batch's stream has finished, 0 while work is pending; never blocks */
+int mrchip_batch_done(mrchip_batch *b);
 int mrchip_batch_sync(mrchip_batch *b);
 int mrchip_batch_box_decisions(mrchip_batch *b, int page, int32_t *decisions, int nb);
 int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask, size_t *mask_pitch,

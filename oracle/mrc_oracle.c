@@ -11,9 +11,10 @@
  * every function here is pinned against the REAL reference run in the build
  * container (oracle/ref_loader.py imports internetarchivepdf/mrc.py and the
  * Cython modules compiled from /root/reference by oracle/build_ref.sh):
- *   - tests/test_oracle_vs_reference.py (runs where /root/reference exists)
- *   - committed golden vectors tests/golden/ (npz files) made by
- *     tests/golden/make_golden.py from the reference itself.
+ *   - committed golden vectors tests/golden/ (npz files, digests.json) made by
+ *     tests/golden/make_golden.py from the reference itself, which also asserts the
+ *     SURVEY.md 8c known-answer digests while it runs (build container only);
+ *   - tests/test_oracle_golden.py compares this file with those vectors anywhere.
  *
  * Each function cites the reference file:line it restates.  Third-party
  * algorithms that the reference reaches through un-vendored dependencies

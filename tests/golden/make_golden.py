@@ -16,6 +16,10 @@ Files written next to this script:
   thirdparty.npz  convert('L'), estimate_sigma, estimate_noise, gaussian_filter, thumbnail
   pages.npz       full create_mrc_hocr_components on small synthetic pages
   digests.json    SHA-256 of outputs at BASELINE.json config sizes
+  configs.json    per-page SHA-256 for the batch configs: 64 distinct config-2 pages (the 512-page stack of
+                  config 4 cycles through them), config-3 pages (3300x4600 gray thresholds and RGB full)
+  modes.npz       small pages in PIL modes other than L / RGB (convert('L') of the original, mrc.py:359-361)
+                  and create_threshold_mask vectors
 """
 import hashlib
 import json
@@ -264,8 +268,83 @@ def digests():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+C2_SEEDS = list(range(202, 266))          # 202 is the page of digests.json's c2_dpiNone; config 4 cycles through these
+C3_GRAY_SEEDS = list(range(303, 311))
+C3_RGB_SEEDS = [303, 304, 305, 306]
+
+
+def _c2_job(seed):
+    img, hocr, m, fg, bg, keys, errs = run_ref_page(4000, 3000, 3, seed, 6.0, None, None, 3, None, 'fast', 60)
+    return str(seed), {'in': sha(img), 'mask': sha(m), 'mask_sum': int(m.sum()), 'fg': sha(fg), 'bg': sha(bg)}
+
+
+def _c3_rgb_job(seed):
+    img, hocr, m, fg, bg, keys, errs = run_ref_page(3300, 4600, 3, seed, 6.0, None, None, 3, None, 'fast', 60)
+    return str(seed), {'in': sha(img), 'mask': sha(m), 'mask_sum': int(m.sum()), 'fg': sha(fg), 'bg': sha(bg),
+                       'bg_shape': list(bg.shape)}
+
+
+def _c3_gray_job(seed):
+    img = synth.synth_page(3300, 4600, 1, seed=seed, noise_sigma=6.0)[0]
+    t = mrc.threshold_image(img, None)
+    return str(seed), {'in': sha(img), 'out': sha(t), 'sum': int(t.sum())}
+
+
+def configs():
+    """Per-page reference digests for the batch configurations (BASELINE.json configs[2], configs[3])."""
+    import multiprocessing as mp
+    out = {}
+    with mp.Pool(6) as pool:
+        out['c2_pages'] = dict(pool.map(_c2_job, C2_SEEDS))
+        out['c3_rgb_pages'] = dict(pool.map(_c3_rgb_job, C3_RGB_SEEDS))
+        out['c3_gray_pages'] = dict(pool.map(_c3_gray_job, C3_GRAY_SEEDS))
+    d = json.load(open(os.path.join(HERE, 'digests.json')))
+    assert out['c2_pages']['202']['mask'] == d['c2_dpiNone']['mask'] and out['c2_pages']['202']['bg'] == d['c2_dpiNone']['bg']
+    assert out['c3_gray_pages']['303']['out'] == d['c3_threshold']['out']
+    with open(os.path.join(HERE, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+MODE_CASES = ['YCbCr', 'CMYK', 'P', 'RGBA', 'LA', '1', 'HSV']
+
+
+def modes():
+    """Pages in PIL modes other than L / RGB through the reference generator, and create_threshold_mask."""
+    d = {}
+    meta = []
+    for i, mode in enumerate(MODE_CASES):
+        rgb, hocr = synth.synth_page(360, 280, 3, seed=900 + i, noise_sigma=5.0, line_div=14)
+        im = Image.fromarray(rgb).convert(mode)
+        td, er = [], set()
+        g = mrc.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast', timing_data=td,
+                                           errors=er)
+        m = next(g).copy(); fg = next(g); bg = next(g)
+        d['md_mask_%d' % i] = np.packbits(m, axis=1)
+        d['md_fg_%d' % i] = fg
+        d['md_bg_%d' % i] = bg
+        meta.append({'mode': mode, 'seed': 900 + i, 'keys': [k for k, _ in td], 'mask_sum': int(m.sum()),
+                     'gray_sha': sha(np.array(im.convert('L'))), 'rgb_sha': sha(np.array(im.convert('RGB')))})
+    d['md_meta'] = np.array(json.dumps(meta))
+    # create_threshold_mask (mrc.py:300-329): in-place OR into a non-empty mask, with and without the blur
+    rng = np.random.RandomState(77)
+    tm = []
+    for i, (w, h, ns, dpi) in enumerate([(300, 220, 6.0, None), (301, 211, 0.4, None), (260, 200, 14.0, 200),
+                                         (180, 140, 3.0, 100)]):
+        gray = synth.synth_page(w, h, 1, seed=950 + i, noise_sigma=ns, line_div=12)[0]
+        m0 = rng.rand(h, w) < 0.02
+        m = m0.copy()
+        td = []
+        mrc.create_threshold_mask(m, np.array(gray, dtype=np.float32), dpi=dpi, denoise_mask='fast', timing_data=td)
+        d['tm_gray_%d' % i] = gray
+        d['tm_in_%d' % i] = np.packbits(m0, axis=1)
+        d['tm_out_%d' % i] = np.packbits(m, axis=1)
+        tm.append({'dpi': dpi, 'keys': [k for k, _ in td], 'sum': int(m.sum())})
+    d['tm_meta'] = np.array(json.dumps(tm))
+    np.savez_compressed(os.path.join(HERE, 'modes.npz'), **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests']
+    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests', 'configs', 'modes']
     for name in which:
         t0 = time.time()
         globals()[name]()

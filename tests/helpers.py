@@ -35,3 +35,15 @@ def kernel_cases(kind):
 def thirdparty_cases(kind):
     z, meta = load_npz('thirdparty.npz')
     return z, [m for m in meta if m[0] == kind]
+
+
+def load_configs():
+    with open(os.path.join(GOLDEN, 'configs.json')) as f:
+        return json.load(f)
+
+
+def sha_many(arrays, threads=16):
+    """sha256 of many arrays on a thread pool (hashlib releases the GIL on large buffers)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(threads, len(arrays)))) as ex:
+        return list(ex.map(sha, arrays))

@@ -1,0 +1,190 @@
+"""GPU tests of the drop-in boundary beyond the three-yield generator: create_threshold_mask, the reference-made
+threshold vectors through mrc.threshold_image, PIL modes other than L / RGB, the bregman passthrough, argument
+checks of the handles, launches with more jobs than a grid dimension holds."""
+import json
+
+import numpy as np
+import pytest
+
+import mrc_oracle as O
+from mrchip import _lib, mrc, synth
+from helpers import GOLDEN, kernel_cases, unpack, sha, load_digests
+
+pytestmark = pytest.mark.gpu
+
+
+def _modes():
+    import os
+    z = np.load(os.path.join(GOLDEN, 'modes.npz'))
+    return z, json.loads(str(z['md_meta'])), json.loads(str(z['tm_meta']))
+
+
+def test_create_threshold_mask_golden():
+    """mrc.create_threshold_mask (mrc.py:300-329) against outputs of the reference itself: in-place OR into a
+    mask that already holds pixels, blur and no-blur pages, timing keys."""
+    z, _, tm = _modes()
+    for i, m in enumerate(tm):
+        gray = z['tm_gray_%d' % i]
+        h, w = gray.shape
+        mask = unpack(z['tm_in_%d' % i], w)
+        td = []
+        ret = mrc.create_threshold_mask(mask, np.array(gray, dtype=np.float32), dpi=m['dpi'], denoise_mask='fast',
+                                        timing_data=td)
+        assert ret is None
+        exp = unpack(z['tm_out_%d' % i], w)
+        assert np.array_equal(mask, exp), (i, int((mask != exp).sum()))
+        assert [k for k, _ in td] == m['keys']
+        assert int(mask.sum()) == m['sum']
+    # a float image that does not hold uint8 values is refused, not approximated
+    with pytest.raises(_lib.MrchipError):
+        mrc.create_threshold_mask(np.zeros((8, 8), bool), np.full((8, 8), 0.5, np.float32))
+    with pytest.raises(_lib.MrchipError):
+        mrc.estimate_noise(np.full((8, 8), 300.0, np.float32))
+    with pytest.raises(ValueError):
+        mrc.create_threshold_mask(np.zeros((8, 9), bool), np.zeros((8, 8), np.float32))
+
+
+def test_threshold_image_reference_vectors():
+    """the KAT2 / thr_out_* vectors made by the reference's threshold_image, through mrc.threshold_image
+    (they only reached the oracle before)"""
+    z, cases = kernel_cases('threshold')
+    assert len(cases) >= 4
+    for (_, j, h, w, dpi, _, k) in cases:
+        img = synth.synth_page(w, h, 1, seed=40 + j, noise_sigma=5.0, line_div=10)[0]
+        out = mrc.threshold_image(img, None if dpi == -1 else dpi, k)
+        assert out.dtype == np.bool_ and out.shape == (h, w)
+        exp = unpack(z['thr_out_%d' % j], w)
+        assert np.array_equal(out, exp), (j, int((out != exp).sum()))
+    pat = synth.kat_pattern(1200, 1600)
+    out = mrc.threshold_image(pat, 124)
+    assert np.array_equal(out, unpack(z['thr_kat2_bits'], 1200))
+    assert sha(out)[:16] == '7e6d215db2679515' and int(out.sum()) == 203520
+    d = load_digests()['c1_threshold']
+    img = synth.synth_page(1200, 1600, 1, seed=101, noise_sigma=6.0)[0]              # BASELINE.json configs[0]
+    assert sha(img) == d['in']
+    t = mrc.threshold_image(img, 124)
+    assert sha(t) == d['out'] and int(t.sum()) == d['sum']
+
+
+def test_pil_modes_other_than_l_and_rgb():
+    """mrc.py:359-361 thresholds image.convert('L') of the ORIGINAL image; mrc.py:401-404 converts to RGB for the
+    layers only.  Reference-made pages in YCbCr, CMYK, P, RGBA, LA, 1, HSV."""
+    Image = pytest.importorskip('PIL.Image')
+    z, md, _ = _modes()
+    for i, m in enumerate(md):
+        rgb, hocr = synth.synth_page(360, 280, 3, seed=m['seed'], noise_sigma=5.0, line_div=14)
+        im = Image.fromarray(rgb).convert(m['mode'])
+        if sha(np.array(im.convert('L'))) != m['gray_sha'] or sha(np.array(im.convert('RGB'))) != m['rgb_sha']:
+            pytest.skip('this Pillow converts mode %s differently from the one that made the vectors' % m['mode'])
+        td = []
+        g = mrc.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast', timing_data=td)
+        mask, fg, bg = next(g), next(g), next(g)
+        exp = unpack(z['md_mask_%d' % i], 360)
+        assert np.array_equal(mask, exp), (m['mode'], int((mask != exp).sum()))
+        assert np.array_equal(fg, z['md_fg_%d' % i]) and np.array_equal(bg, z['md_bg_%d' % i]), m['mode']
+        assert [k for k, _ in td] == m['keys']
+        # the batch form takes the same two planes
+        (bm, bf, bb), = mrc.decompose_pages([im], [hocr], bg_downsample=2)
+        assert np.array_equal(bm, exp) and np.array_equal(bf, fg) and np.array_equal(bb, bg)
+
+
+def test_bregman_is_a_host_passthrough():
+    img, hocr = synth.synth_page(200, 160, 1, seed=3, line_div=10)
+    try:
+        import skimage.restoration  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='bregman')
+    if not have:
+        with pytest.raises(ImportError):
+            next(g)
+        return
+    from skimage.restoration import denoise_tv_bregman
+    td = []
+    g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='bregman', timing_data=td)
+    mask = next(g)
+    e = O.create_mrc_hocr_components(img, hocr, denoise_mask='none')
+    em = next(e)
+    exp = np.array(denoise_tv_bregman(np.array(em, dtype=np.float32), weight=1.) > 0.4, dtype=bool)
+    assert np.array_equal(mask, exp)
+    fg = next(g)
+    assert np.array_equal(fg, O.optimise_gray2(exp.view(np.uint8), img, 200, 160, 3))
+    assert 'denoise' in [k for k, _ in td]
+
+
+def test_upload_mask_replaces_the_mask_for_the_layers():
+    ctx = _lib.default_context()
+    img, hocr = synth.synth_page(300, 200, 3, seed=9, line_div=10)
+    bt = mrc.Batch(ctx, 1, 300, 200, 3)
+    bt.upload(0, img)
+    bt.set_boxes(0, mrc.hocr_boxes(hocr, 300, 200))
+    with pytest.raises(_lib.MrchipError):
+        bt.upload_mask(0, np.zeros((200, 300), bool))          # before mask_finish
+    bt.mask_begin(51)
+    bt.mask_finish(bt.sigmas(), True)
+    rng = np.random.RandomState(5)
+    m2 = rng.rand(200, 300) < 0.1
+    bt.upload_mask(0, m2)
+    assert np.array_equal(bt.download_mask(0), m2)
+    assert np.array_equal(bt.download_mask_packed(0), np.packbits(m2, axis=1))
+    fgs, bgs, _ = bt.layers(None, None)
+    assert np.array_equal(bt.download_layer(0, 0, fgs), O.optimise_rgb2(m2.view(np.uint8), img, 300, 200, 3))
+    assert np.array_equal(bt.download_layer(0, 1, bgs), O.optimise_rgb2((~m2).view(np.uint8), img, 300, 200, 10))
+    bt.close()
+
+
+def test_handles_check_shapes_and_order():
+    ctx = _lib.default_context()
+    bt = mrc.Batch(ctx, 2, 64, 48, 3)
+    with pytest.raises(ValueError):
+        bt.upload(0, np.zeros((48, 64), np.uint8))             # gray into an RGB batch
+    with pytest.raises(ValueError):
+        bt.upload(0, np.zeros((48, 64, 4), np.uint8))          # RGBA
+    with pytest.raises(ValueError):
+        bt.upload(0, np.zeros((40, 64, 3), np.uint8))          # too small: would be read out of bounds
+    with pytest.raises(ValueError):
+        bt.upload(0, np.zeros((48, 64, 3), np.float32))
+    img, hocr = synth.synth_page(64, 48, 3, seed=2, line_div=6)
+    for i in range(2):
+        bt.upload(i, img)
+        bt.set_boxes(i, mrc.hocr_boxes(hocr, 64, 48))
+    bt.mask_begin(51)
+    bt.mask_finish(bt.sigmas(), True)
+    bt.layers(None, 3)
+    m0 = bt.download_mask(0)
+    # new pixels invalidate the finished mask: nothing stale can be downloaded or fed to the layers
+    bt.upload(0, img[::-1].copy())
+    with pytest.raises(_lib.MrchipError):
+        bt.download_mask(0)
+    with pytest.raises(_lib.MrchipError):
+        bt.layers(None, 3)
+    bt.upload(0, img)
+    bt.mask_begin(51)
+    bt.mask_finish(bt.sigmas(), True)
+    assert np.array_equal(bt.download_mask(0), m0)
+    with pytest.raises(_lib.MrchipError):
+        bt.set_count(3)
+    bt.close()
+    with pytest.raises(ValueError):
+        mrc.create_hocr_mask(np.zeros((48, 64), np.uint8), np.zeros((48, 60), bool), hocr)
+
+
+def test_more_boxes_than_a_grid_dimension():
+    """every hOCR box is a job in grid.z (<= 65535): 70 000 small boxes on one page go in two launches"""
+    w, h = 2800, 2000
+    img = synth.synth_page(w, h, 1, seed=21, noise_sigma=5.0, line_div=40)[0]
+    bw, bh, nx = 8, 7, 350
+    boxes = np.array([[(i % nx) * bw, (i // nx) * bh, (i % nx) * bw + bw, (i // nx) * bh + bh] for i in range(70000)],
+                     dtype=np.int32)
+    assert boxes[:, 2].max() <= w and boxes[:, 3].max() <= h
+    mask = np.zeros((h, w), np.uint8)
+    dec = np.zeros(len(boxes), np.int32)
+    ctx = _lib.default_context()
+    _lib.check(_lib.load().mrchip_hocr_mask(ctx.handle, _lib.ptr(img), _lib.ptr(mask), w, h, _lib.ptr(boxes, _lib.i32p),
+                                            len(boxes), 51, _lib.ptr(dec, _lib.i32p)), 'mrchip_hocr_mask')
+    exp = np.zeros((h, w), np.bool_)
+    edec = []
+    O.create_hocr_mask(img, exp, boxes, dpi=None, decisions=edec)
+    assert list(dec) == list(edec)
+    assert np.array_equal(mask.view(np.bool_), exp), int((mask.view(np.bool_) != exp).sum())
