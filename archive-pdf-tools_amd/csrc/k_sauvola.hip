@@ -21,10 +21,23 @@
 // come back from L2 / Infinity Cache).  Algorithmic bytes: 2*w*h.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <vector>
 
 #include "mrchip_internal.h"
 
 namespace mrchip {
+
+// Per window-row-count constants of the fast decision (one record per nrows = 1..wh, count = ww * nrows):
+// exact truncating divisions by `count` as one 32x32->hi multiply + shift each (host-checked magic numbers).
+struct SauvolaRow {
+    unsigned ms, mq;          // floor(S / count) = mulhi(S, ms) >> ss  for 0 <= S <= 255 count;  likewise Q <= 65025 count
+    int ss, sq;
+    unsigned c255, c65025;    // 255 * count, 65025 * count: window sums of the inverted image (255 - p)
+    int ok;                   // magic numbers exist for this count
+    int pad_;
+};
 
 struct SauvolaParams {
     int ww, wh;       // window
@@ -33,6 +46,10 @@ struct SauvolaParams {
     int flags;
     int two;          // output columns per tile
     int th;           // output rows per tile
+    // fast decision (see sauvola_kernel): fp32 copies of the constants + the per-row table; fast == 0: fp64 only
+    int fast;
+    float km1f, k2f;
+    const SauvolaRow *rows;   // [wh + 1], indexed by nrows
 };
 
 
@@ -100,22 +117,80 @@ __device__ __forceinline__ bool sauvola_form_dd(double Sd, double Qd, double pxd
     return kpos ? (neg || (lhs <= rhs)) : (neg && (lhs >= rhs));
 }
 
+// The reference's decision for one pixel from its window sums, out of line: the arbiter of the fast path's near-ties
+// (a pixel in ~10^5).  Kept out of the kernel body so that its fp64 temporaries do not count against the kernel's
+// register budget -- the kernel is latency-bound and lives on waves per SIMD.
+__device__ __attribute__((noinline)) bool sauvola_form_exact(unsigned S, unsigned Q, unsigned px, unsigned count, double km1,
+                                                             double k2, int kpos) {
+    const double rcd = rcp_nr((double)count), hrcd = 0.5 * rcd;
+    return sauvola_form_dd((double)S, (double)Q, (double)px, rcd, hrcd, kpos != 0, km1, k2);
+}
+
+// floor(n / c) for a per-lane divisor (window clipped by the left / right image border): fp32 estimate, within one
+// of the quotient for n / c <= 65025 (relative error 2^-22), then one exact remainder check each way.
+__device__ __forceinline__ unsigned div_lane(unsigned n, unsigned c, float rc) {
+    unsigned q = (unsigned)((float)n * rc);
+    const int rem = (int)(n - q * c);                 // true remainder in (-c, 2c): fits whatever the 32-bit wrap
+    q -= rem < 0 ? 1u : 0u;
+    q += rem >= (int)c ? 1u : 0u;
+    return q;
+}
+
+// ---- asynchronous row loads ----------------------------------------------------------------------------------
+// The three input rows of an output row (entering, leaving, centre) are loaded PF rows ahead into fixed register
+// slots.  hipcc cannot keep such loads in flight across the loop: with a variable number of stores between a load
+// and its use it falls back to `s_waitcnt vmcnt(0)`, which also waits for the loads just issued -- a full memory
+// latency in every row (measured: the kernel's time did not change when its instruction count was halved).  So the
+// loads and their waits are written by hand: the load is an asm statement whose output the compiler believes
+// ready, and every use is preceded by an asm `s_waitcnt vmcnt(N)` that takes the slot as an in/out operand (which
+// also pins the order).  vmcnt retires in order, so N = the number of LOADS issued after the one needed; the
+// compiler's own stores in between can only make the wait stricter, never too weak.  The listing is checked for
+// spills (none) -- a spill or copy of a slot between its load and its wait would read stale registers.
+template <int KD> struct Slot;
+template <> struct Slot<1> { typedef unsigned T; };
+template <> struct Slot<2> { typedef unsigned T __attribute__((ext_vector_type(2))); };
+template <> struct Slot<4> { typedef unsigned T __attribute__((ext_vector_type(4))); };
+
+template <int KD>
+__device__ __forceinline__ void row_load_async(typename Slot<KD>::T &r, unsigned off, const uint8_t *base) {
+    if constexpr (KD == 1) asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    if constexpr (KD == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    if constexpr (KD == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+}
+template <int N, class T>
+__device__ __forceinline__ void rows_wait(T &a, T &b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N, class T>
+__device__ __forceinline__ void rows_wait(T &a) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int KD>
+__device__ __forceinline__ unsigned slot_dword(const typename Slot<KD>::T &r, int q) {
+    if constexpr (KD == 1) return r; else return r[q];
+}
+
 // Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
 // (wh-1)-row warm-up).  (An LDS ring of the last wh rows was tried: it removes the re-reads but
 // caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
-template <int K, bool MULTI>
-__global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
+// BOTH: every job also thresholds the image 255 - p (the hOCR-box launch; a page launch has BOTH = false and does
+// not carry the second polarity's registers).
+template <int K, bool MULTI, bool FAST, bool BOTH>
+__global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
     constexpr int KD = K / 4;
-    constexpr int PF = (K == 8) ? 2 : 4;               // rows in flight
+#ifndef SAUVOLA_PF8
+#define SAUVOLA_PF8 2
+#endif
+    constexpr int PF = (K == 8) ? SAUVOLA_PF8 : 2;     // rows in flight = unroll factor of the row loop
     // Prefix rows in LDS, transposed: strip column ci = K*t + i lives at [i][t + PL].  A wave's
     // accesses for one pixel index i are then consecutive dwords (conflict-free); the natural
     // [ci] order would put lanes 16 B apart = a 4-way bank conflict on every read.  PL lanes of
     // slack on both sides: halo lanes evaluate the formula on out-of-strip indices instead of
     // branching around it (their results are never stored).
     constexpr int PL = 32, LS = 64 + 2 * PL;
-    __shared__ unsigned EsBuf[K * LS];
-    __shared__ unsigned EqBuf[K * LS];
+    // (prefix of sums, prefix of sums of squares) side by side: one 8-byte LDS access per column end instead of two
+    __shared__ uint2 EBuf[K * LS];
     auto pidx = [&](int ci) { const int c2 = ci + K * PL; return (c2 % K) * LS + c2 / K; };
 
     SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
@@ -187,41 +262,58 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         for (int q = 0; q < KD; q++) m[q] = wv[q] & vmask[q];
         acc_row(m, plus);
     };
-    // warm-up: rows [Y0-o, Y0+u-1] (clipped) enter the sums
-    for (int yy = max(0, Y0 - o); yy < min(h, Y0 + u); yy++) {
-        unsigned wv[KD];
-        gload(yy, wv);
-        acc_row_m(wv, true);
+    // warm-up: rows [Y0-o, Y0+u-1] (clipped) enter the sums, four loads in flight at a time
+    {
+        int yy = max(0, Y0 - o);
+        const int ye = min(h, Y0 + u);
+        for (; yy + 4 <= ye; yy += 4) {
+            unsigned wv[4][KD];
+#pragma unroll
+            for (int t = 0; t < 4; t++) gload(yy + t, wv[t]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc_row_m(wv[t], true);
+        }
+        for (; yy < ye; yy++) {
+            unsigned wv[KD];
+            gload(yy, wv);
+            acc_row_m(wv, true);
+        }
     }
-    // three register queues, PF rows deep: entering rows y+u, leaving rows y-o, centre rows y.
+    // three register queues, PF slots each: entering rows y+u, leaving rows y-o, centre rows y.
     // Every address is known in advance, so the loads run PF rows ahead of their use and the
     // serial chain of a row never waits for memory (leaving / centre rows come back from L2/MALL).
-    unsigned qe[PF][KD], ql[PF][KD], qc[PF][KD];
+    typedef typename Slot<KD>::T slot_t;
+    slot_t qe[PF], ql[PF], qc[PF];
     const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
+    auto aload = [&](int yy, slot_t &r) {
+        const int yc = min(max(yy, 0), h - 1);
+        row_load_async<KD>(r, loff, srcA + (size_t)yc * job.src_pitch);     // uniform row base + lane offset
+    };
+    // every load of the loop is issued in this order: e, l (after the column update), c (after the decision)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the warm-up's loads are the compiler's: start from zero
 #pragma unroll
     for (int d = 0; d < PF; d++) {
-        gload(Y0 + u + d, qe[d]);
-        gload(Y0 - o + d, ql[d]);
-        gload(Y0 + d, qc[d]);
+        aload(Y0 + u + d, qe[d]);
+        aload(Y0 - o + d, ql[d]);
+        aload(Y0 + d, qc[d]);
     }
+    constexpr int WAIT_EL = 3 * (PF - 1) + 1;     // loads issued after row y's e/l pair: c(y), then e, l, c of PF-1 rows
+    constexpr int WAIT_C = 3 * (PF - 1) + 2;      // ... after c(y): the same PF-1 rows, plus e(y+PF), l(y+PF)
 
     unsigned ones_a = 0, ones_b = 0;
     const bool kpos = P.k >= 0;
 
-    for (int y = Y0; y < Y0 + rows; y++) {
-        // ---- heads of the queues, then refill PF rows ahead ----
+    // The row loop is unrolled PF times so that each slot of the three queues is a fixed set of registers: row y
+    // reads slot y mod PF and, once it is done with it, loads row y + PF into the same registers.  No register
+    // moves, and a load has PF - 1 whole rows to land (a shifting queue makes every row wait for the load issued
+    // one row earlier, whatever its depth: the shift itself needs the data).
+    int cur_nrows = -1;
+    SauvolaRow RW = {};
+    auto do_row = [&](const int y, slot_t &qev, slot_t &qlv, slot_t &qcv) {
+        rows_wait<WAIT_EL>(qev, qlv);
         unsigned ev[KD], lv[KD], cv[KD];
 #pragma unroll
-        for (int q = 0; q < KD; q++) { ev[q] = qe[0][q]; lv[q] = ql[0][q]; cv[q] = qc[0][q]; }
-#pragma unroll
-        for (int d = 0; d + 1 < PF; d++)
-#pragma unroll
-            for (int q = 0; q < KD; q++) {
-                qe[d][q] = qe[d + 1][q]; ql[d][q] = ql[d + 1][q]; qc[d][q] = qc[d + 1][q];
-            }
-        gload(y + u + PF, qe[PF - 1]);
-        gload(y - o + PF, ql[PF - 1]);
-        gload(y + PF, qc[PF - 1]);
+        for (int q = 0; q < KD; q++) { ev[q] = slot_dword<KD>(qev, q); lv[q] = slot_dword<KD>(qlv, q); }
         // entering row y+u and leaving row y-o together: with d = pe - pl and t = pe + pl per column,
         // S += d and Q += pe^2 - pl^2 = d * t (one signed 24-bit multiply-add); a row outside the image
         // contributes zeros (wave-uniform selects)
@@ -239,7 +331,23 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 }
             }
         }
-        const int nrows = min(y + u, h - 1) - max(y - o, -1);
+        // this slot's next rows (ev / lv are dead from here on).  The loads must be issued AFTER the wait for this
+        // row's data: vmcnt counts in order, so a load issued before that wait is waited for as well (a full memory
+        // latency in every row).  The barrier takes a result of the column update as an operand -- a bare "memory"
+        // clobber orders memory operations only and lets the scheduler sink the (register-only) update below it.
+        asm volatile("" : "+v"(cs[K - 1]), "+v"(cq[0]) : : "memory");
+        aload(y + u + PF, qev);
+        aload(y - o + PF, qlv);
+        const int nrows = __builtin_amdgcn_readfirstlane(min(y + u, h - 1) - max(y - o, -1));
+        if (nrows != cur_nrows) {          // per-count constants: scalar loads, only when the row count changes
+            // constant address space: a uniform load from it is a scalar load (a plain global load would become a
+            // vector load behind the kernel's own stores and put a full-latency vmcnt(0) into the row)
+            typedef const SauvolaRow __attribute__((address_space(4))) *crow_p;
+            const crow_p rp = (crow_p)(uintptr_t)P.rows + nrows;
+            RW.ms = rp->ms; RW.mq = rp->mq; RW.ss = rp->ss; RW.sq = rp->sq;
+            RW.c255 = rp->c255; RW.c65025 = rp->c65025; RW.ok = rp->ok;
+            cur_nrows = nrows;
+        }
 
         // exclusive prefix over the strip's columns
         unsigned ps[K], pqx[K];
@@ -251,63 +359,158 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
         lds_wave_sync();                   // previous row's LDS reads are done
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            EsBuf[i * LS + lane + PL] = bs + ps[i];
-            EqBuf[i * LS + lane + PL] = bq + pqx[i];
+            EBuf[i * LS + lane + PL] = make_uint2(bs + ps[i], bq + pqx[i]);
         }
         lds_wave_sync();
 
         // wave-uniform count / reciprocal when every output of the strip has the full window width
         const unsigned ucount = (unsigned)(P.ww * nrows);
-        const double urcd = rcp_nr((double)ucount), uhrcd = 0.5 * urcd;
+        rows_wait<WAIT_C>(qcv);            // the centre row, loaded PF rows ago
+#pragma unroll
+        for (int q = 0; q < KD; q++) cv[q] = slot_dword<KD>(qcv, q);
 
         unsigned outa[KD], outb[KD];
 #pragma unroll
         for (int q = 0; q < KD; q++) { outa[q] = 0; outb[q] = 0; }
-        bool any = false, all = true;
-#pragma unroll
-        for (int i = 0; i < K; i++) {
+
+        // window sums and count of column i of this lane (S, Q exact integers mod 2^32)
+        auto window = [&](int i, unsigned &S, unsigned &Q, unsigned &count) {
             const int c = c0 + i;
-            const bool valid = (c >= X0) && (c < X0 + nout);
-            any |= valid;
-            all &= valid;
-            // evaluated for every column of the lane, valid or not (no divergent branch per pixel)
             const int ci = K * lane + i;
-            const int ia = pidx(ci + r + 1), ib = pidx(ci - l + 1);
-            const unsigned S = EsBuf[ia] - EsBuf[ib];
-            const unsigned Q = EqBuf[ia] - EqBuf[ib];
-            unsigned count = ucount;
-            double rcd = urcd, hrcd = uhrcd;
+            const uint2 ea = EBuf[pidx(ci + r + 1)], eb = EBuf[pidx(ci - l + 1)];
+            S = ea.x - eb.x; Q = ea.y - eb.y;
+            count = ucount;
             if (!full_cols) {
                 const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
                 count = (unsigned)max(ncols * nrows, 1);
-                rcd = rcp_nr((double)count);
-                hrcd = 0.5 * rcd;
             }
-            const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;     // only valid columns are stored
-            const double Sd = (double)S, Qd = (double)Q, pxd = (double)px;
-            const bool form = sauvola_form_dd(Sd, Qd, pxd, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
-            const unsigned bit = valid ? ((form ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;   // pyx:153 (+ mrc.py:85)
-            outa[i / 4] |= bit << (8 * (i & 3));
-            ones_a += bit;
-            if (job.dst_inv) {
-                // the same window on the image 255-p (mrc.py:224, 235)
-                // sum(255-p) = 255 n - S, sum((255-p)^2) = 65025 n - 510 S + Q: integers below 2^32, exact in
-                // fp64 whatever the rounding of the fmas (three conversions saved)
-                const double cd = (double)count;
-                const double Sid = __builtin_fma(255.0, cd, -Sd);
-                const double Qid = __builtin_fma(-510.0, Sd, __builtin_fma(65025.0, cd, Qd));
-                const bool fi = sauvola_form_dd(Sid, Qid, 255.0 - pxd, rcd, hrcd, kpos, P.km1, P.k2);
-                const unsigned bi = valid ? ((fi ? 0u : 1u) ^ (invert ? 1u : 0u)) : 0u;
-                outb[i / 4] |= bi << (8 * (i & 3));
-                ones_b += bi;
+        };
+        if constexpr (!FAST) {
+            // ---- general path: the reference's decision in fp64 in its own operation order (any k, R, window) ----
+            // one reciprocal per row where the whole strip sees the full window width (the count is uniform then)
+            const double urcd = rcp_nr((double)ucount), uhrcd = 0.5 * urcd;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                unsigned S, Q, count;
+                window(i, S, Q, count);
+                double rcd = urcd, hrcd = uhrcd;
+                if (!full_cols) { rcd = rcp_nr((double)count); hrcd = 0.5 * rcd; }
+                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
+                const double Sd = (double)S, Qd = (double)Q, pxd = (double)px;
+                const bool fa = sauvola_form_dd(Sd, Qd, pxd, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
+                outa[i / 4] |= fa ? (1u << (8 * (i & 3))) : 0u;
+                if constexpr (BOTH) {
+                    // the same window on the image 255-p (mrc.py:224, 235)
+                    // sum(255-p) = 255 n - S, sum((255-p)^2) = 65025 n - 510 S + Q: integers below 2^32, exact in
+                    // fp64 whatever the rounding of the fmas (three conversions saved)
+                    const double cd = (double)count;
+                    const double Sid = __builtin_fma(255.0, cd, -Sd);
+                    const double Qid = __builtin_fma(-510.0, Sd, __builtin_fma(65025.0, cd, Qd));
+                    const bool fb = sauvola_form_dd(Sid, Qid, 255.0 - pxd, rcd, hrcd, kpos, P.km1, P.k2);
+                    outb[i / 4] |= fb ? (1u << (8 * (i & 3))) : 0u;
+                }
+            }
+        } else {
+            // ---- fast decision (0 < k <= 1) -----------------------------------------------------------------------
+            // mean and floor(Q / count) exactly, as integers; the comparison in fp32 on the signed square t|t|
+            // (t <= 0 or t^2 <= rhs  <=>  t|t| <= rhs for rhs >= 0).  The fp32 value of t is within 2.3e-5 of the exact
+            // one and the right-hand side within 1.8e-7 relative, so |t|t| - rhs| > 4e-4 |t| + 1e-8 settles the
+            // comparison the reference makes in fp64 (derivation in DESIGN.md 3); a lane inside that band -- a pixel
+            // in ~10^5 -- is re-decided by sauvola_form_exact.  A window of mean 0 has rhs = 0 and t = p exactly:
+            // nothing to arbitrate (all-black regions would otherwise send every pixel there).
+            const float C1 = 4e-4f, C3 = 1e-8f;
+            unsigned unc_a = 0, unc_b = 0;            // wave-uniform: columns i where some lane sits on a near-tie
+            auto fast_px = [&](float mean, float qf, float pxf, unsigned &out, unsigned &unc_cols, int i) {
+                const float mm = mean * mean;
+                const float var = qf - mm;
+                const float t = __builtin_fmaf(mean, P.km1f, pxf);
+                const float d = t * __builtin_fabsf(t) - (mm * P.k2f) * var;
+                const bool unc = (__builtin_fabsf(d) <= __builtin_fmaf(__builtin_fabsf(t), C1, C3)) & (mean != 0.0f);
+                unc_cols |= __builtin_amdgcn_ballot_w64(unc) ? (1u << i) : 0u;
+                out |= (d <= 0.0f) ? (1u << (8 * (i & 3))) : 0u;                      // form
+            };
+            auto fast_row = [&](auto both, auto uniform) {
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    unsigned S, Q, count;
+                    window(i, S, Q, count);
+                    const float pxf = (float)((cv[i / 4] >> (8 * (i & 3))) & 0xffu);
+                    if constexpr (decltype(uniform)::value) {
+                        // one count for the whole row: magic-number divisions (SauvolaRow)
+                        fast_px((float)(__umulhi(S, RW.ms) >> RW.ss), (float)(__umulhi(Q, RW.mq) >> RW.sq), pxf,
+                                outa[i / 4], unc_a, i);
+                        if constexpr (decltype(both)::value) {    // the window on 255 - p: sums from S, Q and the count
+                            const unsigned Si = RW.c255 - S, Qi = (Q + RW.c65025) - 510u * S;
+                            fast_px((float)(__umulhi(Si, RW.ms) >> RW.ss), (float)(__umulhi(Qi, RW.mq) >> RW.sq),
+                                    255.0f - pxf, outb[i / 4], unc_b, i);
+                        }
+                    } else {
+                        // strips at the left / right image border (or a row count without magic numbers)
+                        const float rc = __builtin_amdgcn_rcpf((float)count);
+                        fast_px((float)div_lane(S, count, rc), (float)div_lane(Q, count, rc), pxf, outa[i / 4], unc_a, i);
+                        if constexpr (decltype(both)::value) {
+                            const unsigned Si = 255u * count - S, Qi = (Q + 65025u * count) - 510u * S;
+                            fast_px((float)div_lane(Si, count, rc), (float)div_lane(Qi, count, rc), 255.0f - pxf,
+                                    outb[i / 4], unc_b, i);
+                        }
+                    }
+                }
+            };
+            const bool uni = full_cols && RW.ok;
+            if (uni) fast_row(std::integral_constant<bool, BOTH>{}, std::true_type{});
+            else fast_row(std::integral_constant<bool, BOTH>{}, std::false_type{});
+            if (unc_a | unc_b) {                  // rare
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    if (!(((unc_a | unc_b) >> i) & 1u)) continue;
+                    unsigned S, Q, count;
+                    window(i, S, Q, count);
+                    const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
+                    const unsigned bit = 1u << (8 * (i & 3));
+                    const bool fa = sauvola_form_exact(S, Q, px, count, P.km1, P.k2, 1);
+                    outa[i / 4] = (outa[i / 4] & ~bit) | (fa ? bit : 0u);
+                    if constexpr (BOTH) {
+                        const bool fb = sauvola_form_exact(255u * count - S, (Q + 65025u * count) - 510u * S, 255u - px, count,
+                                                           P.km1, P.k2, 1);
+                        outb[i / 4] = (outb[i / 4] & ~bit) | (fb ? bit : 0u);
+                    }
+                }
             }
         }
+        // form -> stored value (pyx:153 `0 if formres else 1`, complemented for mrc.py:85's np.invert), columns
+        // outside the strip's outputs cleared, set pixels counted
+        bool any = false, all = true;
+#pragma unroll
+        for (int q = 0; q < KD; q++) {
+            unsigned vm = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = c0 + 4 * q + b;
+                const bool valid = (c >= X0) && (c < X0 + nout);
+                any |= valid;
+                all &= valid;
+                vm |= valid ? (1u << (8 * b)) : 0u;
+            }
+            outa[q] = (invert ? outa[q] : ~outa[q]) & vm;
+            ones_a += __builtin_popcount(outa[q]);
+            if constexpr (BOTH) {
+                outb[q] = (invert ? outb[q] : ~outb[q]) & vm;
+                ones_b += __builtin_popcount(outb[q]);
+            }
+        }
+        asm volatile("" : "+v"(outa[0]), "+v"(outa[KD - 1]) : : "memory");     // as above: after the last use of cv
+        aload(y + PF, qcv);                // the slot's next centre row (cv is dead from here on)
         if (any) {
-            uint8_t *d = job.dst + (size_t)y * job.dst_pitch + c0;
-            const bool aligned = (reinterpret_cast<uintptr_t>(d) & 3u) == 0;
+            // global (not flat) stores: a flat access also counts on lgkmcnt -- every LDS wait of the next row would
+            // wait for it -- and may retire out of order with the global loads, which the counted vmcnt waits of the
+            // row queues cannot tolerate (seen as rare wrong tiles before the address space was pinned)
+            typedef uint8_t __attribute__((address_space(1))) *g_u8p;
+            typedef unsigned __attribute__((address_space(1))) *g_u32p;
+            g_u8p d = (g_u8p)(uintptr_t)(job.dst + (size_t)y * job.dst_pitch + c0);
+            const bool aligned = (((uintptr_t)d) & 3u) == 0;
             if (all && aligned) {
 #pragma unroll
-                for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(d)[q] = outa[q];
+                for (int q = 0; q < KD; q++) ((g_u32p)d)[q] = outa[q];
             } else {
 #pragma unroll
                 for (int i = 0; i < K; i++) {
@@ -318,11 +521,11 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                     }
                 }
             }
-            if (job.dst_inv) {
-                uint8_t *e = job.dst_inv + (size_t)y * job.dst_pitch + c0;
+            if constexpr (BOTH) {
+                g_u8p e = (g_u8p)(uintptr_t)(job.dst_inv + (size_t)y * job.dst_pitch + c0);
                 if (all && aligned) {
 #pragma unroll
-                    for (int q = 0; q < KD; q++) reinterpret_cast<unsigned *>(e)[q] = outb[q];
+                    for (int q = 0; q < KD; q++) ((g_u32p)e)[q] = outb[q];
                 } else {
 #pragma unroll
                     for (int i = 0; i < K; i++) {
@@ -333,7 +536,13 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
                 }
             }
         }
+    };
+    for (int yb = Y0; yb < Y0 + rows; yb += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; d++)
+            if (yb + d < Y0 + rows) do_row(yb + d, qe[d], ql[d], qc[d]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the queue's last loads (rows past the tile) land before the registers are reused
     if (job.counts) {
         unsigned a = wave_sum(ones_a);
         unsigned b = wave_sum(ones_b);
@@ -342,6 +551,48 @@ __global__ __launch_bounds__(64) void sauvola_kernel(SauvolaJob job1, const Sauv
             if (b) atomicAdd(&job.counts[1], b);
         }
     }
+}
+
+// floor(n / c) == mulhi(n, m) >> sh for every 0 <= n <= nmax, with m = ceil(2^(32+sh) / c) < 2^32: true iff
+// (m c - 2^(32+sh)) nmax < 2^(32+sh) (Granlund-Montgomery).  The largest shift whose multiplier fits 32 bits
+// is the most accurate one, so only that one is tried.
+static bool magic_for(unsigned long long c, unsigned long long nmax, unsigned *m, int *sh) {
+    if (c < 2) return false;                              // 2^32 / 1 does not fit the multiplier
+    for (int s = 31; s >= 0; s--) {
+        const unsigned __int128 p = (unsigned __int128)1 << (32 + s);
+        const unsigned __int128 mm = (p + c - 1) / c;
+        if (mm >> 32) continue;
+        const unsigned __int128 e = mm * c - p;
+        if (e * nmax < p) { *m = (unsigned)mm; *sh = s; return true; }
+        return false;
+    }
+    return false;
+}
+
+// Row tables are a function of the window only: built once per (ww, wh) and kept for the life of the process
+// (a few hundred bytes each).  Returns the device copy, nullptr if it cannot be made.
+static const SauvolaRow *row_table(mrchip_ctx *ctx, int ww, int wh, std::vector<SauvolaRow> *host_copy = nullptr) {
+    struct Entry { int dev, ww, wh; SauvolaRow *d; std::vector<SauvolaRow> h; };
+    static std::vector<Entry> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : cache)
+        if (e.dev == ctx->device && e.ww == ww && e.wh == wh) { if (host_copy) *host_copy = e.h; return e.d; }
+    Entry e;
+    e.dev = ctx->device; e.ww = ww; e.wh = wh; e.d = nullptr;
+    e.h.assign(wh + 1, SauvolaRow{});
+    for (int nr = 1; nr <= wh; nr++) {
+        SauvolaRow &r = e.h[nr];
+        const unsigned long long c = (unsigned long long)ww * nr;
+        r.c255 = (unsigned)(255ull * c); r.c65025 = (unsigned)(65025ull * c);
+        r.ok = 65025ull * c <= 0xffffffffull && magic_for(c, 255ull * c, &r.ms, &r.ss) &&
+               magic_for(c, 65025ull * c, &r.mq, &r.sq);
+    }
+    if (hipMalloc((void **)&e.d, e.h.size() * sizeof(SauvolaRow)) != hipSuccess) return nullptr;
+    if (hipMemcpy(e.d, e.h.data(), e.h.size() * sizeof(SauvolaRow), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache.push_back(e);
+    if (host_copy) *host_copy = e.h;
+    return e.d;
 }
 
 template <int K>
@@ -363,12 +614,25 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     P.th = th;
     dim3 grid(strips, cdiv(maxh, th), njobs);
     const char *nm = (njobs == 1 && !d_jobs) ? "sauvola" : (h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola");
-    if (njobs == 1 && !d_jobs)
-        LAUNCH(ctx, s, nm, alg_bytes,
-               hipLaunchKernelGGL((sauvola_kernel<K, false>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
-    else
-        LAUNCH(ctx, s, nm, alg_bytes,
-               hipLaunchKernelGGL((sauvola_kernel<K, true>), grid, dim3(64), 0, s, h_jobs[0], d_jobs, P));
+    const bool single = njobs == 1 && !d_jobs;
+    const bool both = h_jobs[0].dst_inv != nullptr;
+    for (int i = 1; i < njobs; i++)
+        if ((h_jobs[i].dst_inv != nullptr) != both) { set_error("sauvola: jobs with and without a second polarity in one launch"); return MRCHIP_E_ARG; }
+#define SAUVOLA_LAUNCH(MULTI_, FAST_, BOTH_)                                                                     \
+    LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_>), grid, dim3(64), 0, s, \
+                                                     h_jobs[0], d_jobs, P))
+    const int sel = (single ? 0 : 4) | (P.fast ? 2 : 0) | (both ? 1 : 0);
+    switch (sel) {
+        case 0: SAUVOLA_LAUNCH(false, false, false); break;
+        case 1: SAUVOLA_LAUNCH(false, false, true); break;
+        case 2: SAUVOLA_LAUNCH(false, true, false); break;
+        case 3: SAUVOLA_LAUNCH(false, true, true); break;
+        case 4: SAUVOLA_LAUNCH(true, false, false); break;
+        case 5: SAUVOLA_LAUNCH(true, false, true); break;
+        case 6: SAUVOLA_LAUNCH(true, true, false); break;
+        default: SAUVOLA_LAUNCH(true, true, true); break;
+    }
+#undef SAUVOLA_LAUNCH
     return 0;
 }
 
@@ -421,6 +685,18 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
     P.l = (ww + 1) / 2; P.r = ww / 2; P.o = (wh + 1) / 2; P.u = wh / 2;
     P.k = k; P.km1 = k - 1; P.k2 = k * k / R / R;     // pyx:62
     P.flags = flags;
+    // fast decision: 0 < k <= 1 (|k - 1| <= 1 bounds the fp32 error of t), a right-hand-side factor that is a
+    // normal fp32 number, a window of at least two pixels whose sum of squares fits 32 bits
+    // The fp32 / integer "fast" decision is kept as a measured experiment: on gfx950 an fp64 fma, mul,
+    // add or conversion issues at the same ~4.3 cycles per wave as an fp32 or integer one (profiles/r02_valu_rates.txt),
+    // so the guarded path executes as many instructions per pixel as the exact one (SQ_INSTS_VALU 55.8 vs 53.2 per
+    // pixel-wave) and is not faster.  MRCHIP_SAUVOLA_FAST=1 selects it; the parity tests run it both ways.
+    const char *fast_env = getenv("MRCHIP_SAUVOLA_FAST");
+    const int no_fast = !(fast_env && atoi(fast_env) != 0);
+    P.km1f = (float)P.km1; P.k2f = (float)P.k2;
+    P.rows = row_table(ctx, ww, wh);
+    if (!P.rows) { set_error("sauvola: cannot allocate the row table"); return MRCHIP_E_NOMEM; }
+    P.fast = !no_fast && k > 0 && k <= 1 && P.k2 > 1e-30 && P.k2 < 1e30 && (long long)ww * wh >= 2;
     int maxw = 0, maxh = 0;
     double alg = 0;
     for (int i = 0; i < njobs; i++) {
