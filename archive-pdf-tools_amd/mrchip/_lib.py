@@ -88,6 +88,12 @@ SIGNATURES = {
     'mrchip_batch_box_decisions': (C.c_int, [vp, C.c_int, i32p, C.c_int]),
     'mrchip_batch_device_ptrs': (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t),
                                            C.POINTER(vp), C.POINTER(vp)]),
+    'mrchip_comm_unique_id': (C.c_int, [u8p]),
+    'mrchip_comm_init': (vp, [vp, C.c_int, C.c_int, u8p]),
+    'mrchip_comm_destroy': (None, [vp]),
+    'mrchip_comm_bcast': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_int]),
+    'mrchip_comm_allgather': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mrchip_comm_allreduce_f64': (C.c_int, [vp, f64p, C.c_int, C.c_int]),
     'mrchip_prof_enable': (C.c_int, [vp, C.c_int]),
     'mrchip_prof_reset': (C.c_int, [vp]),
     'mrchip_prof_count': (C.c_int, [vp]),

@@ -306,6 +306,7 @@ class Batch:
             raise _lib.MrchipError('mrchip_batch_create: %s' % _lib.last_error())
         self._wtab = np.zeros((npages, _lib.MAX_TAPS), dtype=np.float64)
         self._radius = np.zeros(npages, dtype=np.int32)
+        self._sources = []          # host arrays of uploads that may still be in flight
 
     def close(self):
         if self._h:
@@ -319,7 +320,10 @@ class Batch:
             pass
 
     def upload(self, page, arr):
+        """Enqueue the copy of one page.  The source array is referenced until the batch's stream is next waited
+        for: the HIP runtime may copy from page-locked AND from ordinary host memory after this call returns."""
         arr = _checked_page(arr, self.w, self.h, self.c, 'page')
+        self._sources.append(arr)
         _lib.check(self.lib.mrchip_batch_upload(self._h, page, _lib.ptr(arr)), 'mrchip_batch_upload')
 
     def upload_gray(self, page, gray):
@@ -350,6 +354,7 @@ class Batch:
     def sigmas(self):
         s = np.zeros(self.n, dtype=np.float64)
         _lib.check(self.lib.mrchip_batch_sigmas(self._h, _lib.ptr(s, _lib.f64p)), 'mrchip_batch_sigmas')
+        self._sources = []          # the call waited for the stream: every upload has landed
         return s
 
     def mask_finish(self, sigmas, denoise_fast=True):
@@ -457,8 +462,42 @@ class _StreamSlot:
         self.out.clear()
 
 
+class StreamPool:
+    """The device batches and page-locked result arrays of decompose_stream, kept between calls: creating them
+    (tens of GB of hipMalloc / hipHostMalloc for 4000x3000 pages) costs more than decomposing a few hundred pages,
+    so a long-running caller makes one pool and passes it to every decompose_stream(..., pool=pool)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.free = {}             # (n, w, h, c) -> [idle _StreamSlot]
+        self.every = []
+
+    def take(self, n, w, h, c):
+        idle = self.free.setdefault((n, w, h, c), [])
+        if idle:
+            return idle.pop()
+        sl = _StreamSlot(self.ctx, n, w, h, c)
+        self.every.append(sl)
+        return sl
+
+    def give(self, slot):
+        self.free[slot.key].append(slot)
+
+    def close(self):
+        for sl in self.every:
+            sl.close()
+        self.every, self.free = [], {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
-                     denoise_mask=DENOISE_FAST, ctx=None, batch_pages=32, slots=3, mask_format='bool', copy=False):
+                     denoise_mask=DENOISE_FAST, ctx=None, batch_pages=32, slots=3, mask_format='bool', copy=False,
+                     pool=None, stats=None):
     """The page loop of recode.py:291-492 as a pipeline: `pages` is an iterable of (image, hocr_word_data);
     yields (mask, fg, bg) per page, in input order, equal to what create_mrc_hocr_components yields for it.
 
@@ -472,44 +511,56 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
     mask_format: 'bool' -- bool[h,w] like the reference's first yield; 'packed' -- uint8[h,(w+7)//8], 1 bit per
     pixel MSB first (PIL mode '1' / PBM rows, what mrc.encode_mrc_mask builds for jbig2; an eighth of the bytes).
     copy=False hands out views of the pinned result arrays, valid until `batch_pages` further pages have been
-    taken from the generator; copy=True returns arrays the caller owns."""
+    taken from the generator; copy=True returns arrays the caller owns.  pool: a StreamPool to take the device
+    batches and result arrays from (and leave them in); without one they are made and released by this call.
+    stats: a dict that receives the host wall time spent in each phase (upload, boxes, phase A enqueue, the sigma
+    wait, phase B + layers + download enqueue, the final wait) -- where a slow stream loses its time."""
     if denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
         raise ValueError('Invalid denoise option:', denoise_mask)     # bregman is a host pass: use the generator
     if mask_format not in ('bool', 'packed'):
         raise ValueError("mask_format must be 'bool' or 'packed'")
     if slots < 3 or batch_pages < 1:
         raise ValueError('decompose_stream: slots >= 3 and batch_pages >= 1 expected')
-    ctx = ctx or _lib.default_context()
+    own_pool = pool is None
+    if own_pool:
+        pool = StreamPool(ctx)
+    ctx = pool.ctx
     window = _window_size(dpi)
-    free = {}                  # (n, w, h, c) -> [idle _StreamSlot]
-    every = []
+    take_slot = pool.take
 
-    def take_slot(n, w, h, c):
-        pool = free.setdefault((n, w, h, c), [])
-        if pool:
-            return pool.pop()
-        sl = _StreamSlot(ctx, n, w, h, c)
-        every.append(sl)
-        return sl
+    def tick(key, seconds):
+        if stats is not None:
+            stats[key] = stats.get(key, 0.0) + seconds
 
     def fill(items):
         h, w = items[0][0].shape[:2]
         c = 1 if items[0][0].ndim == 2 else 3
         job = _StreamJob(take_slot(batch_pages, w, h, c), items)
         bt = job.slot.batch
+        t0 = time()
         for j, (arr, gray, hocr) in enumerate(items):
             bt.upload(j, arr)
             if gray is not None:
                 bt.upload_gray(j, gray)
+        t1 = time()
+        for j, (arr, gray, hocr) in enumerate(items):
             bt.set_boxes(j, hocr_boxes(hocr, w, h, downsample))
         bt.set_count(len(items))                     # a short last batch leaves the other pages untouched
+        t2 = time()
         bt.mask_begin(window)
+        tick('upload_s', t1 - t0)
+        tick('boxes_s', t2 - t1)
+        tick('phase_a_enqueue_s', time() - t2)
         return job
 
     def mid(job):
         bt = job.slot.batch
         n, w, h, c = job.slot.key
-        bt.mask_finish(bt.sigmas(), denoise_mask == DENOISE_FAST)
+        t0 = time()
+        sig = bt.sigmas()
+        t1 = time()
+        tick('sigma_wait_s', t1 - t0)
+        bt.mask_finish(sig, denoise_mask == DENOISE_FAST)
         fgs, bgs, _ = bt.layers(fg_downsample, bg_downsample)
         job.sizes = (fgs, bgs)
         mshape = (n, h, (w + 7) // 8) if mask_format == 'packed' else (n, h, w)
@@ -523,10 +574,13 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
                 bt.download_mask(j, out=m[j], wait=False)
             bt.download_layer(j, 0, fgs, out=fg[j], wait=False)
             bt.download_layer(j, 1, bgs, out=bg[j], wait=False)
+        tick('phase_b_enqueue_s', time() - t1)
 
     def drain(job):
         bt = job.slot.batch
+        t0 = time()
         bt.sync()
+        tick('final_wait_s', time() - t0)
         m, fg, bg = job.slot.out['mask'], job.slot.out['fg'], job.slot.out['bg']
         for j in range(len(job.items)):
             mj = m[j] if mask_format == 'packed' else m[j].view(np.bool_)
@@ -535,7 +589,7 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
             else:
                 yield mj, fg[j], bg[j]
         job.items = None
-        free[job.slot.key].append(job.slot)
+        pool.give(job.slot)
 
     inflight = []                # jobs in pipeline order; [-1] filled, [-2] ready for mid, [0] drains next
 
@@ -564,8 +618,14 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
         while inflight:
             yield from drain(inflight.pop(0))
     finally:
-        for sl in every:
-            sl.close()
+        for job in inflight:           # abandoned mid-stream: wait for what is queued, return the slots
+            try:
+                job.slot.batch.sync()
+            except Exception:
+                pass
+            pool.give(job.slot)
+        if own_pool:
+            pool.close()
 
 
 def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,

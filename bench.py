@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark: pages/s of the full MRC decomposition (mask + fg + bg) of
-4000x3000 RGB pages with hOCR boxes, bg downsample 3 -- BASELINE.json configs[1] --
-on N MI355X GPUs of one node, one process per GPU, pages sharded across ranks with no
-data-path collective.
+"""Headline benchmark: pages/s of the full MRC decomposition (mask + fg + bg) of 4000x3000 RGB pages with hOCR
+boxes, bg downsample 3 -- BASELINE.json configs[1] -- on N MI355X GPUs of one node, one process per GPU, pages
+sharded across ranks (page i -> rank i mod N) with no data-path collective.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          (any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE)
 
-A "step" = one pass of the hot path over this rank's batch of --pages pages whose pixels
-are already resident in HBM (outputs stay in HBM; the PCIe-inclusive drop-in rate is
-printed as `pcie_inclusive_pages_per_s`, it is never `value`).  Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path over this rank's --pages pages whose pixels are already resident in HBM;
+outputs stay in HBM.  Rank 0 prints ONE JSON line.  Beside `value` the line carries, all measured in this run:
 
-roofline: the kernel with the largest share of GPU time, measured with HIP events on the
-stream each launch goes to (mrchip_prof_*), algorithmic bytes per SURVEY.md 8d.
-cpu_baseline: the C restatement of the reference (oracle/, kind "port") timed on this
-host's cores on a bounded sample of the same workload.
+  roofline        the kernel with the largest share of GPU time: algorithmic bytes / launch time from HIP events
+                  on the stream each launch goes to (mrchip_prof_*); `isolated`: the same batches one at a time
+  cpu_baseline    the C restatement of the reference (oracle/, kind "port") on this host's cores (N = 1 only)
+  e2e             the PCIe-inclusive rate of the streaming page pipeline (mrc.decompose_stream: host arrays in,
+                  packed mask + fg + bg thumbnails out, upload / compute / download of three rotating batches
+                  overlapped), with the measured link rates -- never `value`
+  parity          SHA-256 of the outputs of the pages this run decomposed against the digests the REFERENCE produced
+                  for the same synthetic pages (tests/golden/configs.json); at N > 1 the 512-page stack of
+                  configs[3] is sharded, every rank's records are gathered on rank 0 and all 512 are checked
+
+--config c3 | c3gray | c5 run the other BASELINE.json configurations with the same JSON shape (c3gray: the
+Sauvola-only batch whose HBM GB/s is BASELINE's second metric).  The control plane between ranks is RCCL through
+libmrchip (mrchip_comm_*): no PyTorch anywhere in this process.
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,64 +38,89 @@ sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-W, H, C = 4000, 3000, 3
-BG_DOWNSAMPLE = 3
-DISTINCT = 4                # distinct synthetic pages, cycled through the batch
+PCIE_SPEC_GBS = 63.0        # PCIe Gen5 x16 per direction (MI355X_MICROARCH.md)
+REFERENCE_PAGES_PER_S_PER_CORE = 0.33   # the reference itself on configs[1], BASELINE.md 2 (survey container, 1 core)
+
+CONFIGS = {
+    'c2': dict(label='configs[1]: 4000x3000 RGB page + hOCR line boxes, dpi=None (window 51), bg_downsample=3, '
+                     'denoise fast, full create_mrc_hocr_components',
+               w=4000, h=3000, c=3, dpi=None, bg=3, fg=None, pages=384, inflight=3, distinct=16, line_div=60,
+               seeds=list(range(202, 266)), digests='c2_pages', metric='pages/sec MRC decompose (4000x3000 RGB)'),
+    'c3': dict(label='configs[2] (RGB): batch of 64 pages 3300x4600 RGB + hOCR, window 51, bg_downsample=3, full decomposition',
+               w=3300, h=4600, c=3, dpi=None, bg=3, fg=None, pages=64, inflight=1, distinct=4, line_div=60,
+               seeds=[303, 304, 305, 306], digests='c3_rgb_pages', metric='pages/sec MRC decompose (3300x4600 RGB)'),
+    'c3gray': dict(label='configs[2] (gray): batch of 64 pages 3300x4600 gray, Sauvola window 51 k=0.34 only (threshold_image)',
+                   w=3300, h=4600, c=1, dpi=None, bg=None, fg=None, pages=64, inflight=1, distinct=8, line_div=60,
+                   seeds=list(range(303, 311)), digests='c3_gray_pages', metric='Sauvola HBM GB/s (64 x 3300x4600 gray)'),
+    'c5': dict(label='configs[4]: 8000x6000 RGB + hOCR, dpi=364 (window 91), fg and bg downsample 4',
+               w=8000, h=6000, c=3, dpi=364, bg=4, fg=4, pages=32, inflight=2, distinct=2, line_div=60,
+               seeds=[505, 506], digests=None, metric='pages/sec MRC decompose (8000x6000 RGB)'),
+}
+STACK_PAGES = 512            # BASELINE.json configs[3]: the 512-page stack, sharded page i -> rank i mod N
 
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def make_pages(n_distinct, rank):
-    from mrchip import synth, mrc
-    pages = []
-    for i in range(n_distinct):
-        seed = 202 + i + 1000 * rank          # seed 202 is the page the reference digested (digests.json)
-        img, hocr = synth.synth_page(W, H, C, seed=seed, noise_sigma=6.0, line_div=60)
-        boxes = mrc.hocr_boxes(hocr, W, H)
-        pages.append((img, hocr, boxes))
-    return pages
+def sha_many(arrays, threads=32):
+    from concurrent.futures import ThreadPoolExecutor
+    if not arrays:
+        return []
+    with ThreadPoolExecutor(max(1, min(threads, len(arrays)))) as ex:
+        return list(ex.map(sha, arrays))
 
 
-def cpu_baseline(sample_pages):
-    """oracle (C port of the reference) on `sample_pages`: one worker thread per host core, each
-    decomposing whole pages (the C calls release the GIL), plus a single-thread run for the
-    per-core figure.  Bounded: ~12 s for the all-core run, ~6 s single-thread."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import threading
-    import mrc_oracle as O
-    O.lib()
-
-    def decompose(i):
-        img, hocr, _ = sample_pages[i % len(sample_pages)]
-        for _ in O.create_mrc_hocr_components(img, hocr, dpi=None, bg_downsample=BG_DOWNSAMPLE, denoise_mask='fast'):
-            pass
-
-    def run(nthreads, seconds):
-        done = [0] * nthreads
-        t0 = time.time()
-
-        def worker(k):
-            i = k
-            while time.time() - t0 < seconds:
-                decompose(i)
-                i += nthreads
-                done[k] += 1
-        th = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return sum(done), time.time() - t0
-
+def ncpus():
     try:
-        ncpu = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        ncpu = os.cpu_count() or 1
-    nthr = max(1, min(ncpu, 32))                    # ~0.4 GB of numpy temporaries per in-flight page
-    n1, dt1 = run(1, 6.0)
-    nall, dtall = (n1, dt1) if nthr == 1 else run(nthr, 12.0)
+        return os.cpu_count() or 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: runs BEFORE anything touches the GPU (worker processes are forked)
+def _cpu_worker(args):
+    k, seconds, cfg = args
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mrc_oracle as O
+    from mrchip import synth
+    O.lib()
+    img, hocr = synth.synth_page(cfg['w'], cfg['h'], cfg['c'], seed=cfg['seeds'][k % len(cfg['seeds'])], noise_sigma=6.0,
+                                 line_div=cfg['line_div'])
+    done = 0
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        if cfg['bg'] is None and cfg['fg'] is None and cfg['c'] == 1:
+            O.threshold_image(img, cfg['dpi'])
+        else:
+            for _ in O.create_mrc_hocr_components(img, hocr, dpi=cfg['dpi'], bg_downsample=cfg['bg'],
+                                                  fg_downsample=cfg['fg'], denoise_mask='fast'):
+                pass
+        done += 1
+    return done, time.time() - t0
+
+
+def cpu_baseline(cfg, seconds=12.0):
+    """The oracle (C restatement of the reference, kind "port") decomposing pages of this workload on every host core:
+    one worker PROCESS per core (each synthesises its own page, then decomposes it in a loop for `seconds`), bounded by
+    the free memory (~1.2 GB per in-flight 4000x3000 page with its numpy temporaries); plus one worker alone for the
+    per-core figure."""
+    import multiprocessing as mp
+    ncpu = ncpus()
+    per_worker = 1.2e9 * (cfg['w'] * cfg['h'] * cfg['c']) / 36e6
+    try:
+        with open('/proc/meminfo') as f:
+            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
+    except Exception:
+        avail = 32 << 30
+    workers = int(max(1, min(ncpu, 0.5 * avail / per_worker)))
+    ctx = mp.get_context('fork')
+    with ctx.Pool(1) as pool:
+        n1, dt1 = pool.map(_cpu_worker, [(0, seconds / 2, cfg)])[0]
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(k, seconds, cfg) for k in range(workers)])
+    rate = sum(n / dt for n, dt in res)
     model = ''
     try:
         with open('/proc/cpuinfo') as f:
@@ -97,10 +130,42 @@ def cpu_baseline(sample_pages):
                     break
     except OSError:
         pass
-    return {'value': round(nall / dtall, 4), 'unit': 'pages/s', 'cores': nthr, 'kind': 'port',
-            'sample': '%d decompositions of the same 4000x3000 RGB pages through oracle/mrc_oracle.c (-O3), %d threads, %.1f s'
-                      % (nall, nthr, dtall),
-            'single_thread_value': round(n1 / dt1, 4), 'host_cpus': ncpu, 'cpu_model': model}
+    return {'value': round(rate, 3), 'unit': 'pages/s', 'cores': workers, 'kind': 'port',
+            'sample': '%d decompositions of this workload through oracle/mrc_oracle.c (gcc -O3, no fast-math: it is also '
+                      'the bit-exact checker), %d worker processes x %.0f s, one page each in flight'
+                      % (sum(n for n, _ in res), workers, seconds),
+            'single_thread_value': round(n1 / dt1, 4), 'host_cpus': ncpu, 'cpu_model': model,
+            'reference_itself_pages_per_s_per_core': REFERENCE_PAGES_PER_S_PER_CORE,
+            'note': 'cores = worker processes actually used (all host cores unless memory-bound); the reference figure is '
+                    'the Python/Cython reference on configs[1] measured in the survey container (BASELINE.md)'}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def git_head():
+    try:
+        return subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def pmc_traffic(name, alg_per_launch):
+    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
+    2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size -- with the provenance, so a
+    stale profile cannot pass for a measurement of this build."""
+    sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
+           'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
+        d = json.load(open(f))
+        src = {'file': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
+        for k, v in d['kernels'].items():
+            if sym in k and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
+                return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch']), src
+        return None, src
+    except Exception:
+        return None, None
 
 
 def main():
@@ -108,76 +173,82 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--pages', type=int, default=384, help='pages per GPU per step')
-    ap.add_argument('--inflight', type=int, default=3, help='device batches in flight per GPU (one HIP stream each)')
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--pages', type=int, default=None, help='pages per GPU per step (default: per config)')
+    ap.add_argument('--inflight', type=int, default=None, help='device batches in flight per GPU (one HIP stream each)')
+    ap.add_argument('--distinct', type=int, default=None, help='distinct synthetic pages per GPU, cycled through the batch')
+    ap.add_argument('--e2e-pages', type=int, default=256, help='pages per GPU pushed through the streaming pipeline (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='skip the untimed parity / PCIe-inclusive section (profiling runs)')
+    ap.add_argument('--no-extras', action='store_true', help='timed region only (profiling runs)')
     a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k in ('pages', 'inflight', 'distinct'):
+        if getattr(a, k) is not None:
+            cfg[k] = getattr(a, k)
+    W, H, Cc = cfg['w'], cfg['h'], cfg['c']
+    sauvola_only = a.config == 'c3gray'
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_
-        # RCCL ("nccl") on the node; MRCHIP_DIST_BACKEND=gloo lets the launch path be exercised on a
-        # single-GPU box (two ranks cannot share one GPU under RCCL)
-        backend = os.environ.get('MRCHIP_DIST_BACKEND', 'nccl')
-        ndev = max(1, torch.cuda.device_count())
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank % ndev)
-            dist_.init_process_group('nccl', device_id=torch.device('cuda', local_rank % ndev))
-        else:
-            dist_.init_process_group(backend)
-        dist = dist_
 
-    from mrchip import _lib, mrc
-    ctx = _lib.Context(local_rank % max(1, _lib.mrchip_visible_devices()))
+    # the CPU baseline forks worker processes: before the first GPU call of this process
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_extras:
+        cpu = cpu_baseline(cfg)
+
+    from mrchip import _lib, mrc, synth
+    from mrchip import dist as mdist
     lib = _lib.load()
+    ctx = _lib.Context(local_rank % max(1, _lib.mrchip_visible_devices()))
     info = ctx.info()
+    comm = mdist.RcclComm(ctx, rank, world) if world > 1 else mdist.SoloComm()
 
-    # work queue: rank 0 owns the descriptor table and broadcasts it over RCCL (bytes, not pixels);
-    # every rank then takes the pages i with i mod world == rank
-    if dist is not None:
-        from mrchip import dist as mdist
-        desc = mdist.broadcast_descriptor(dist, {'w': W, 'h': H, 'pages_per_rank': a.pages, 'distinct': DISTINCT}
-                                          if rank == 0 else None)
-        assert (desc['w'], desc['h'], desc['pages_per_rank']) == (W, H, a.pages)
+    # ---- work queue: rank 0 owns the descriptor table and broadcasts it over RCCL (bytes, not pixels); page j of the
+    # global list (world * pages-per-GPU pages) belongs to rank j mod world and is the synthetic page of seed
+    # seeds[j mod len(seeds)] -- the pages the reference digested (tests/golden/configs.json)
+    desc = comm.bcast_obj({'config': a.config, 'w': W, 'h': H, 'c': Cc, 'pages_per_rank': cfg['pages'], 'seeds': cfg['seeds'],
+                           'distinct': cfg['distinct']} if rank == 0 else None)
+    seeds = desc['seeds']
+    my_global = mdist.shard_pages(world * desc['pages_per_rank'], rank, world)
+    # at most `distinct` different images per rank: the t-th page of this rank shows image t mod distinct
+    slot_seed = [seeds[my_global[t] % len(seeds)] for t in range(min(desc['distinct'], len(my_global)))]
+    made = synth.synth_pages([dict(w=W, h=H, channels=Cc, seed=s, noise_sigma=6.0, line_div=cfg['line_div']) for s in slot_seed])
+    host_pages = [(img, hocr, mrc.hocr_boxes(hocr, W, H)) for img, hocr in made]
+    nd = len(host_pages)
+    window = mrc._window_size(cfg['dpi'])
 
-    host_pages = make_pages(DISTINCT, rank)
-    window = 51                                    # dpi=None (bin/compress-pdf-images:66-70)
-    # the rank's pages are split into `inflight` device batches, each on its own HIP stream, so that
-    # the latency-bound row-sequential kernels of one batch overlap the streaming kernels of another
-    nb = max(1, min(a.inflight, a.pages))
-    sizes = [a.pages // nb + (1 if i < a.pages % nb else 0) for i in range(nb)]
-    batches = []
+    # the rank's pages are split into `inflight` device batches, each on its own HIP stream, so that the
+    # latency-bound row-sequential kernels of one batch overlap the streaming kernels of another
+    nb = max(1, min(cfg['inflight'], cfg['pages']))
+    sizes = [cfg['pages'] // nb + (1 if i < cfg['pages'] % nb else 0) for i in range(nb)]
+    batches, first_of = [], {}
     k = 0
-    for sz in sizes:
-        bt = mrc.Batch(ctx, sz, W, H, C)
+    for bi, sz in enumerate(sizes):
+        bt = mrc.Batch(ctx, sz, W, H, Cc)
         for i in range(sz):
-            img, hocr, boxes = host_pages[k % DISTINCT]
+            img, hocr, boxes = host_pages[k % nd]
             bt.upload(i, img)
             bt.set_boxes(i, boxes)
+            first_of.setdefault(k % nd, (bi, i))        # where the first copy of each distinct image sits
             k += 1
         batches.append(bt)
-    batch = batches[0]
     ctx.sync()
 
     def step():
+        if sauvola_only:
+            for bt in batches:
+                bt.threshold(cfg['dpi'], 0.34)           # one Sauvola launch per batch
+            return
         for bt in batches:
-            bt.mask_begin(window)                    # luma, hOCR-box thresholds, noise estimate
+            bt.mask_begin(window)                        # luma, hOCR-box thresholds, noise estimate
         for bt in batches:
-            bt.mask_finish(bt.sigmas(), True)        # host: Gaussian tables; decisions, blur, Sauvola, denoise
-            bt.layers(None, BG_DOWNSAMPLE)           # fg + bg optimise (one launch), bg thumbnail
+            bt.mask_finish(bt.sigmas(), True)            # host: Gaussian tables; decisions, blur, Sauvola, denoise
+            bt.layers(cfg['fg'], cfg['bg'])              # fg + bg optimise (one launch), thumbnails
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            if dist.get_backend() == 'nccl':
-                import torch
-                torch.cuda.synchronize()
-            dist.barrier()
+        comm.barrier()
 
     for _ in range(a.warmup):
         step()
@@ -188,14 +259,11 @@ def main():
     for _ in range(a.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = comm.max_f64(time.perf_counter() - t0)
     prof = ctx.prof_report()
     ctx.prof_enable(False)
-    if dist is not None:
-        from mrchip import dist as mdist
-        dt = mdist.max_over_ranks(dist, dt)
 
-    # untimed: parity evidence + PCIe-inclusive drop-in rate on rank 0
+    # ------------------------------------------------------------------------------------------- untimed extras
     extra = {}
     prof_iso = None
     if rank == 0 and not a.no_extras and nb > 1:
@@ -207,69 +275,84 @@ def main():
             for bt in batches:
                 bt.mask_begin(window)
                 bt.mask_finish(bt.sigmas(), True)
-                bt.layers(None, BG_DOWNSAMPLE)
+                bt.layers(cfg['fg'], cfg['bg'])
                 ctx.sync()
         prof_iso = ctx.prof_report()
         ctx.prof_enable(False)
+
+    if not a.no_extras:
+        # ---- parity: every distinct page this rank decomposed, digests against the reference's
+        want = {}
+        try:
+            with open(os.path.join(ROOT, 'tests', 'golden', 'configs.json')) as f:
+                want = json.load(f).get(cfg['digests'] or '', {})
+        except Exception:
+            pass
+        recs = []
+        for slot, seed in enumerate(slot_seed):
+            bi, i = first_of[slot]
+            bt = batches[bi]
+            m = bt.download_mask(i)
+            if sauvola_only:
+                hm = sha(m)
+                ok = (str(seed) in want and hm == want[str(seed)]['out'])
+                recs.append({'page': my_global[slot], 'rank': rank, 'seed': seed, 'mask_popcount': int(m.sum()), 'mask': hm,
+                             'checked': str(seed) in want, 'ok': bool(ok)})
+                continue
+            fg = bt.download_layer(i, 0, _layer_size(W, H, cfg['fg']))
+            bg = bt.download_layer(i, 1, _layer_size(W, H, cfg['bg']))
+            hm, hf, hb = sha_many([m, fg, bg], 3)
+            w_ = want.get(str(seed))
+            ok = bool(w_ and (hm, hf, hb) == (w_['mask'], w_['fg'], w_['bg']))
+            recs.append({'page': my_global[slot], 'rank': rank, 'seed': seed, 'mask_popcount': int(m.sum()), 'mask': hm, 'fg': hf,
+                         'bg': hb, 'checked': bool(w_), 'ok': ok})
+        allrecs = [r for part in comm.allgather_obj(recs) for r in part]
+        if rank == 0:
+            checked = [r for r in allrecs if r['checked']]
+            extra['parity'] = {'pages_checked': len(checked), 'mismatches': sum(1 for r in checked if not r['ok']),
+                               'ranks_reporting': len(set(r['rank'] for r in allrecs)),
+                               'against': 'SHA-256 of mask / fg / bg made by the reference for the same synthetic pages '
+                                          '(tests/golden/configs.json)'}
+            if a.config == 'c5':
+                try:
+                    d5 = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')))['c5']
+                    r0 = [r for r in allrecs if r['seed'] == 505]
+                    extra['parity'] = {'pages_checked': len(r0), 'mismatches': sum(1 for r in r0 if (r['mask'], r['fg'], r['bg']) !=
+                                                                                 (d5['mask'], d5['fg'], d5['bg'])),
+                                       'against': 'tests/golden/digests.json c5 (reference)'}
+                except Exception as e:     # pragma: no cover
+                    extra['parity'] = {'error': str(e)}
+
+    for bt in batches:
+        bt.close()
+    batches = []
+
+    if not a.no_extras and not sauvola_only and a.e2e_pages > 0:
+        e2e = e2e_stream(ctx, comm, mrc, cfg, host_pages, a.e2e_pages, rank, world)
+        if rank == 0:
+            extra['e2e'] = e2e
+    if not a.no_extras and a.config == 'c2':
+        st = stack_check(ctx, comm, mrc, synth, cfg, rank, world)
+        if rank == 0:
+            extra['config4_stack'] = st
     if rank == 0 and not a.no_extras:
-        mask = batch.download_mask(0)
-        try:
-            with open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')) as f:
-                dg = json.load(f)['c2_dpiNone']
-            extra['parity'] = 'mask sha256 %s the reference digest' % ('==' if sha(mask) == dg['mask'] else '!=')
-        except Exception as e:     # pragma: no cover
-            extra['parity'] = 'unchecked: %s' % e
-        img, hocr, _ = host_pages[0]
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            for _ in mrc.create_mrc_hocr_components(img, hocr, dpi=None, bg_downsample=BG_DOWNSAMPLE,
-                                                    denoise_mask='fast', ctx=ctx):
-                pass
-        extra['pcie_inclusive_pages_per_s'] = round(reps / (time.perf_counter() - t1), 2)
-        # layer hand-off: D2H rate of one full-resolution layer, pageable vs pinned destination
-        try:
-            pg = np.empty((H, W, C), np.uint8)
-            pin = ctx.pinned_empty((H, W, C))
-            for name, dstarr in (('pageable', pg), ('pinned', pin)):
-                batch.download_layer(0, 0, (W, H), out=dstarr)
-                t2 = time.perf_counter()
-                for _ in range(3):
-                    batch.download_layer(0, 0, (W, H), out=dstarr)
-                extra['d2h_layer_GBps_' + name] = round(3 * pg.nbytes / (time.perf_counter() - t2) / 1e9, 1)
-        except Exception as e:     # pragma: no cover
-            extra['d2h_layer_GBps_error'] = str(e)
         # measured ceiling to read the roofline fractions against: D2D copy, read + write bytes
         extra['hbm_copy_GBps_measured'] = round(ctx.hbm_copy_bandwidth(1 << 30, 10), 1)
 
-    total_pages = a.pages * a.steps * world
-    value = total_pages / dt
+    # ------------------------------------------------------------------------------------------------ the line
+    total_pages = cfg['pages'] * a.steps * world
+    step_s = dt / a.steps
+
     def roofline_of(name, prof=prof):
         r = prof[name]
         ms = r['ms'] / r['launches']
         alg = r['alg_bytes'] / r['launches']
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic, src = pmc_traffic(name, alg)
         return {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(name, alg),
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': src,
                 'avg_launch_ms': round(ms, 4), 'launches': r['launches'], 'alg_bytes_per_launch': alg}
 
-    def pmc_traffic(name, alg_per_launch):
-        """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
-        2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size."""
-        sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
-               'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
-        try:
-            import glob
-            f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
-            d = json.load(open(f))
-            for k, v in d['kernels'].items():
-                if sym in k and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
-                    return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch'])
-        except Exception:
-            pass
-        return None
-
-    # dominant kernel by GPU time
     dom = max(prof.items(), key=lambda kv: kv[1]['ms']) if prof else None
     roof = roofline_of(dom[0]) if dom else None
     sauvola_roof = roofline_of('sauvola') if 'sauvola' in prof else None
@@ -284,27 +367,167 @@ def main():
             sauvola_roof['isolated'] = {'achieved': si['achieved'], 'frac': si['frac'], 'avg_launch_ms': si['avg_launch_ms']}
     kernels = {k: {'ms_per_launch': round(v['ms'] / v['launches'], 4), 'launches': v['launches'],
                    'alg_GBps': round(v['alg_bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in sorted(prof.items())}
+    alg_per_step = sum(v['alg_bytes'] for v in prof.values()) / max(a.steps, 1)
     if rank == 0:
-        cpu = None if a.no_cpu_baseline else cpu_baseline(host_pages)
+        if sauvola_only:
+            value = (2.0 * W * H * total_pages) / dt / 1e9            # BASELINE: 2 * W * H * N_pages / t
+            unit = 'GB/s'
+        else:
+            value = total_pages / dt
+            unit = 'pages/s'
         line = {
-            'metric': 'pages/sec MRC decompose (4000x3000 RGB)', 'value': round(value, 2), 'unit': 'pages/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'metric': cfg['metric'], 'value': round(value, 2), 'unit': unit,
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(step_s * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: 4000x3000 RGB page + hOCR line boxes, dpi=None (window 51), '
-                                   'bg_downsample=3, denoise fast, full create_mrc_hocr_components',
-                       'pages_per_gpu_per_step': a.pages, 'batches_in_flight': nb, 'distinct_pages': DISTINCT,
-                       'hocr_boxes_per_page': int(len(host_pages[0][2])), 'sharding': 'pages round-robin over ranks'},
+            'config': {'workload': cfg['label'], 'pages_per_gpu_per_step': cfg['pages'], 'batches_in_flight': nb,
+                       'distinct_pages_per_gpu': nd, 'hocr_boxes_per_page': int(len(host_pages[0][2])),
+                       'sharding': 'page i of the global list -> rank i mod N (RCCL carries descriptors, records and the time only)'},
             'roofline': roof, 'cpu_baseline': cpu,
+            'pipeline_alg_GBps': round(alg_per_step / step_s / 1e9, 1),      # all kernels' algorithmic bytes / step time
+            'pages_per_s': round(total_pages / dt, 2),
             'sauvola_roofline': sauvola_roof,      # BASELINE.json also names "Sauvola HBM GB/s"
-            'kernels': kernels, 'device': info['name'].strip(),
+            'kernels': kernels, 'device': info['name'].strip(), 'head': git_head(),
         }
         line.update(extra)
         print(json.dumps(line))
-    for bt in batches:
-        bt.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
+
+
+def _layer_size(w, h, ds):
+    """(width, height) of a layer after mrc.py:422-428's thumbnail (host-side size rule of the library)"""
+    if not ds:
+        return (w, h)
+    import ctypes as C
+    from mrchip import _lib
+    ow, oh = C.c_int(), C.c_int()
+    _lib.load().mrchip_thumbnail_size(w, h, int(w / ds), int(h / ds), C.byref(ow), C.byref(oh))
+    return (ow.value, oh.value)
+
+
+def link_rates(ctx):
+    """Measured PCIe rates of this GPU with page-locked host memory, one direction at a time (GB/s)."""
+    import ctypes as C
+    from mrchip import _lib, mrc
+    w, h = 8000, 6000                       # 144 MB per copy
+    bt = mrc.Batch(ctx, 1, w, h, 3)
+    pin = ctx.pinned_empty((h, w, 3))
+    pin[...] = 1
+    out = {}
+    bt.upload(0, pin)
+    ctx.sync()
+    t = time.perf_counter()
+    for _ in range(4):
+        bt.upload(0, pin)
+    ctx.sync()
+    out['h2d_GBps'] = round(4 * pin.nbytes / (time.perf_counter() - t) / 1e9, 1)
+    # D2H of the same plane through the mask-free path: the image plane is not downloadable, so time a layer instead
+    bt.set_boxes(0, np.zeros((0, 4), np.int32))
+    bt.mask_begin(51)
+    bt.mask_finish(bt.sigmas(), True)
+    size, _, _ = bt.layers(None, None, which=1)
+    bt.download_layer(0, 0, size, out=pin)
+    t = time.perf_counter()
+    for _ in range(4):
+        bt.download_layer(0, 0, size, out=pin, wait=False)
+    bt.sync()
+    out['d2h_GBps'] = round(4 * pin.nbytes / (time.perf_counter() - t) / 1e9, 1)
+    bt.close()
+    return out
+
+
+def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
+    """PCIe-inclusive throughput of the streaming pipeline: `n_pages` host pages per rank in, packed mask + fg + bg
+    out into page-locked arrays, every rank at once (so that host-side contention between ranks shows)."""
+    from mrchip import _lib
+    W, H, Cc = cfg['w'], cfg['h'], cfg['c']
+    nd = len(host_pages)
+    res = {}
+    link = link_rates(ctx) if rank == 0 else None
+    pool = mrc.StreamPool(ctx)        # device batches + page-locked result arrays made once, as a long-running caller would
+    for mode in ('pageable', 'pinned'):
+        if mode == 'pinned':       # the page source decodes into page-locked arrays: uploads are asynchronous DMAs
+            src = []
+            for img, hocr, _ in host_pages[:min(nd, 8)]:
+                p = ctx.pinned_empty(img.shape)
+                p[...] = img
+                src.append((p, hocr))
+        else:
+            src = [(img, hocr) for img, hocr, _ in host_pages]
+        gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
+                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=32, mask_format='packed', pool=pool)
+        warm = 0
+        for _ in gen:                   # first pass also allocates the slots: run the stream twice, time the second
+            warm += 1
+        comm.barrier()
+        phases = {}
+        gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
+                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=32, mask_format='packed', pool=pool,
+                                   stats=phases)
+        t0 = time.perf_counter()
+        n = 0
+        out_bytes = 0
+        for m, fg, bg in gen:
+            n += 1
+            out_bytes = m.nbytes + fg.nbytes + bg.nbytes
+        ctx.sync()
+        comm.barrier()
+        dt = comm.max_f64(time.perf_counter() - t0)
+        in_bytes = W * H * Cc
+        res[mode] = {'pages_per_s': round(n * world / dt, 1), 'h2d_GBps_per_gpu': round(n * in_bytes / dt / 1e9, 1),
+                     'd2h_GBps_per_gpu': round(n * out_bytes / dt / 1e9, 1), 'seconds': round(dt, 3),
+                     'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}
+    pool.close()
+    best = max(res.values(), key=lambda r: r['pages_per_s'])
+    out = {'pages_per_s': best['pages_per_s'], 'pages_per_gpu': n_pages, 'batch_pages': 32, 'slots': 3,
+           'host_arrays': res, 'bytes_in_per_page': W * H * Cc, 'bytes_out_per_page': out_bytes,
+           'what': 'mrc.decompose_stream: host page arrays in (pageable numpy / page-locked), packed 1-bpp mask + fg + bg '
+                   'thumbnail out into page-locked arrays; upload, compute and download of three rotating batches overlap'}
+    if link:
+        out['link_measured'] = link
+        out['link_spec_GBps_per_direction'] = PCIE_SPEC_GBS
+        lim = min(link['h2d_GBps'] / (W * H * Cc / 1e9), link['d2h_GBps'] / (out_bytes / 1e9))
+        out['link_ceiling_pages_per_s_per_gpu'] = round(lim, 1)
+        out['frac_of_link_ceiling'] = round(best['pages_per_s'] / world / lim, 3)
+    return out
+
+
+def stack_check(ctx, comm, mrc, synth, cfg, rank, world):
+    """BASELINE.json configs[3]: ONE 512-page stack (the 64 reference-digested pages, mixed), page i -> rank i mod N;
+    every rank streams its shard, digests every output, the records are gathered on rank 0 and all 512 are checked."""
+    with open(os.path.join(ROOT, 'tests', 'golden', 'configs.json')) as f:
+        want = json.load(f)['c2_pages']
+    seeds = sorted(int(s) for s in want)
+    mine = list(range(rank, STACK_PAGES, world))
+    need = sorted(set(seeds[(i * 5) % len(seeds)] for i in mine))
+    made = dict(zip(need, synth.synth_pages([dict(w=cfg['w'], h=cfg['h'], channels=3, seed=s, noise_sigma=6.0, line_div=60)
+                                             for s in need])))
+    t0 = time.perf_counter()
+    recs, pend = [], []
+    gen = mrc.decompose_stream(((made[seeds[(i * 5) % len(seeds)]][0], made[seeds[(i * 5) % len(seeds)]][1]) for i in mine),
+                               bg_downsample=3, batch_pages=32, mask_format='bool', ctx=ctx)
+    for i, (m, fg, bg) in zip(mine, gen):
+        pend.append((i, m, fg, bg))
+        if len(pend) == 16 or i == mine[-1]:          # views stay valid for batch_pages (32) further pages
+            hs = sha_many([x for p in pend for x in p[1:]])
+            for k, p in enumerate(pend):
+                recs.append({'page': p[0], 'rank': rank, 'mask_popcount': int(np.count_nonzero(p[1])), 'mask': hs[3 * k],
+                             'fg': hs[3 * k + 1], 'bg': hs[3 * k + 2]})
+            pend = []
+    dt = comm.max_f64(time.perf_counter() - t0)
+    allrecs = [r for part in comm.allgather_obj(recs) for r in part]
+    if rank != 0:
+        return None
+    bad = 0
+    for r in allrecs:
+        w_ = want[str(seeds[(r['page'] * 5) % len(seeds)])]
+        if (r['mask'], r['fg'], r['bg'], r['mask_popcount']) != (w_['mask'], w_['fg'], w_['bg'], w_['mask_sum']) or \
+                r['rank'] != r['page'] % world:
+            bad += 1
+    return {'pages': len(allrecs), 'distinct': len(seeds), 'all_pages_present': sorted(r['page'] for r in allrecs) == list(range(STACK_PAGES)),
+            'mismatches': bad, 'seconds_incl_hashing': round(dt, 2),
+            'what': '512-page stack sharded page i -> rank i mod N, per-page {page, rank, mask_popcount, sha256 x3} records '
+                    'gathered over RCCL and checked against the reference digests on rank 0'}
 
 
 if __name__ == '__main__':

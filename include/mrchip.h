@@ -223,6 +223,23 @@ int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *mismatches);
  * against every value 0..255*count. */
 int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches);
 
+/* ---- page sharding across GPUs: control-plane collectives over RCCL ---------------------------------------
+ * Pages are independent (recode.py:291's loop body reads only page idx): one process per GPU, page i -> rank
+ * i mod G, no pixel ever crosses ranks.  What does cross is bytes of control data -- the page descriptor table
+ * and flattened hOCR boxes from rank 0, per-page result records back, the maximum of the elapsed times -- and it
+ * goes through these calls (librccl.so, opened at run time).  Rank 0 makes the id with mrchip_comm_unique_id and
+ * hands its 128 bytes to the other ranks by any side channel (mrchip/dist.py uses a file). */
+typedef struct mrchip_comm mrchip_comm;
+int mrchip_comm_unique_id(unsigned char *id128);
+mrchip_comm *mrchip_comm_init(mrchip_ctx *ctx, int rank, int world, const unsigned char *id128);
+void mrchip_comm_destroy(mrchip_comm *c);
+/* `bytes` of host memory from rank `root` to every rank, in place */
+int mrchip_comm_bcast(mrchip_comm *c, void *buf, size_t bytes, int root);
+/* every rank contributes `bytes`; recv[world * bytes] holds the contributions in rank order on every rank */
+int mrchip_comm_allgather(mrchip_comm *c, const void *send, size_t bytes, void *recv);
+/* op 0: sum, 1: max over ranks of n doubles, in place (n = 1 doubles as the barrier) */
+int mrchip_comm_allreduce_f64(mrchip_comm *c, double *vals, int n, int op);
+
 /* ---- measurement --------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the stream each kernel is launched on.
  * enable: 0 off, 1 on.  Kernels are named as in the kernel trace. */

@@ -14,15 +14,17 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, os.path.join(%r, 'archive-pdf-tools_amd'))
     from mrchip import dist as mdist
     dist.init_process_group('gloo')
-    rank, world = dist.get_rank(), dist.get_world_size()
+    comm = mdist.TorchComm(dist)
+    rank, world = comm.rank, comm.world
     # rank 0 owns the work queue; every rank derives its own shard from the broadcast descriptor
-    desc = mdist.broadcast_descriptor(dist, {'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202} if rank == 0 else None)
+    desc = comm.bcast_obj({'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202, 'boxes': [[1, 2, 30, 40]] * 3} if rank == 0 else None)
     mine = mdist.shard_pages(desc['pages'], rank, world)
-    elapsed = mdist.max_over_ranks(dist, 1.0 + rank)            # slowest rank defines the step time
-    gathered = mdist.gather_records(dist, [{'page': p, 'rank': rank} for p in mine])
+    elapsed = comm.max_f64(1.0 + rank)                          # slowest rank defines the step time
+    parts = comm.allgather_obj([{'page': p, 'rank': rank, 'pad': 'x' * (rank * 7)} for p in mine])
+    gathered = [r for part in parts for r in part]
     if rank == 0:
         print(json.dumps({'desc': desc, 'elapsed': elapsed, 'records': gathered}))
-    dist.barrier()
+    comm.barrier()
     dist.destroy_process_group()
 ''')
 
@@ -46,7 +48,7 @@ def test_two_rank_sharding_gloo(tmp_path):
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
-    assert out['desc'] == {'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202}
+    assert out['desc'] == {'w': 4000, 'h': 3000, 'pages': 10, 'seed0': 202, 'boxes': [[1, 2, 30, 40]] * 3}
     assert out['elapsed'] == 2.0
     pages = sorted(rec['page'] for rec in out['records'])
     assert pages == list(range(10))                              # every page exactly once
@@ -62,3 +64,15 @@ def test_shard_pages_properties():
             shards = [mdist.shard_pages(n, r, world) for r in range(world)]
             assert sorted(p for s in shards for p in s) == list(range(n))
             assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_solo_comm_and_rendezvous_name():
+    sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+    from mrchip import dist as mdist
+    c = mdist.SoloComm()
+    assert c.bcast_obj({'a': [1, 2]}) == {'a': [1, 2]}
+    assert c.allgather_obj({'r': 0}) == [{'r': 0}]
+    assert c.max_f64(3.5) == 3.5
+    c.barrier()
+    p = mdist.rendezvous_path()
+    assert os.path.basename(p).startswith('mrchip_rccl_id_')
