@@ -10,6 +10,7 @@ Two transports with one interface (bcast_obj / allgather_obj / max_f64 / barrier
 import ctypes as C
 import json
 import os
+import sys
 import tempfile
 import time
 
@@ -79,7 +80,14 @@ class RcclComm(_Comm):
         path = rendezvous or rendezvous_path()
         ident = (C.c_uint8 * 128)()
         if rank == 0:
-            _lib.check(self.lib.mrchip_comm_unique_id(ident), 'mrchip_comm_unique_id')
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                _lib.check(self.lib.mrchip_comm_unique_id(ident), 'mrchip_comm_unique_id')
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
             tmp = path + '.tmp'
             with open(tmp, 'wb') as f:
                 f.write(bytes(ident))
@@ -93,7 +101,15 @@ class RcclComm(_Comm):
             with open(path, 'rb') as f:
                 raw = f.read()
             C.memmove(ident, raw, 128)
-        self._h = self.lib.mrchip_comm_init(ctx.handle, rank, world, ident)
+        # RCCL prints a version banner on stdout when a communicator is made; a benchmark's stdout is its result line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            self._h = self.lib.mrchip_comm_init(ctx.handle, rank, world, ident)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         if not self._h:
             raise _lib.MrchipError('mrchip_comm_init: %s' % _lib.last_error())
         self._path = path
@@ -156,9 +172,13 @@ class TorchComm(_Comm):
 
 
 def rendezvous_path():
-    """File through which rank 0 hands the RCCL unique id to the other ranks of this launch (one node): named
-    after the launcher's MASTER_PORT and run id so that concurrent launches do not collide."""
-    tag = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
+    """File through which rank 0 hands the RCCL unique id to the other ranks of this launch (one node).  Named after
+    the launcher's MASTER_PORT, run id and process id (the ranks of one launch are children of one launcher process),
+    so that neither a concurrent launch nor the leftover of a crashed one can be mistaken for it;
+    MRCHIP_RENDEZVOUS overrides the path for launchers that do not fork the ranks from one parent."""
+    if os.environ.get('MRCHIP_RENDEZVOUS'):
+        return os.environ['MRCHIP_RENDEZVOUS']
+    tag = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
     tag = ''.join(ch if ch.isalnum() or ch in '_-' else '_' for ch in tag)
     return os.path.join(tempfile.gettempdir(), 'mrchip_rccl_id_%s_%d' % (tag, os.getuid()))
 

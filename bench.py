@@ -202,7 +202,16 @@ def main():
     lib = _lib.load()
     ctx = _lib.Context(local_rank % max(1, _lib.mrchip_visible_devices()))
     info = ctx.info()
-    comm = mdist.RcclComm(ctx, rank, world) if world > 1 else mdist.SoloComm()
+    if world == 1:
+        comm = mdist.SoloComm()
+    elif os.environ.get('MRCHIP_BENCH_COMM') == 'gloo':
+        # test hook: the N > 1 logic of this file on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
+        # GPU); the ranks then share GPU local_rank mod visible-devices
+        import torch.distributed as tdist
+        tdist.init_process_group('gloo')
+        comm = mdist.TorchComm(tdist)
+    else:
+        comm = mdist.RcclComm(ctx, rank, world)
 
     # ---- work queue: rank 0 owns the descriptor table and broadcasts it over RCCL (bytes, not pixels); page j of the
     # global list (world * pages-per-GPU pages) belongs to rank j mod world and is the synthetic page of seed
