@@ -142,10 +142,18 @@ def cpu_baseline(cfg, seconds=12.0):
 
 # ---------------------------------------------------------------------------------------------------------------
 def git_head():
+    """commit of this tree: git where there is a repository, else the stamp build() left beside the library"""
     try:
-        return subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        h = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True,
+                           timeout=10).stdout.strip()
+        if h:
+            return h
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, 'archive-pdf-tools_amd', 'lib', 'BUILD_HEAD')) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

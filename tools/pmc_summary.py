@@ -57,9 +57,24 @@ def main():
         wcsv = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         wcsv.writeheader()
         wcsv.writerows(rows)
+    # algorithmic bytes per launch of the kernels bench.py quotes traffic for, from the bench line of the kernel-trace
+    # pass (so that bench.py can scale the counters to its own launch size), and the commit that was profiled
+    scale, head = {}, None
+    try:
+        with open(os.path.join(src, 'kt_bench.log')) as f:
+            line = [ln for ln in f.read().splitlines() if ln.startswith('{')][-1]
+        b = json.loads(line)
+        head = b.get('head')
+        for key in ('roofline', 'sauvola_roofline'):
+            r = b.get(key)
+            if r:
+                scale[r['kernel']] = {'alg_bytes_per_launch': r['alg_bytes_per_launch'], 'avg_launch_ms_hip_events': r['avg_launch_ms']}
+        shutil.copy(os.path.join(src, 'kt_bench.log'), os.path.join(out, tag + '_bench_under_rocprof.log'))
+    except Exception as e:
+        print('no bench line in kt_bench.log:', e)
     with open(os.path.join(out, tag + '_pmc_summary.json'), 'w') as f:
         json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py ' + note,
-                   'bench_args': note, 'kernels': {r['kernel']: r for r in rows}}, f, indent=1)
+                   'bench_args': note, 'head': head, 'scale': scale, 'kernels': {r['kernel']: r for r in rows}}, f, indent=1)
     for r in rows[:12]:
         print('%-45s n=%3d  read %.3f GB  write %.3f GB  avg %.3f ms' % (r['kernel'][:45], r['launches'],
               r['read_bytes_per_launch_gfx950_corrected'] / 1e9, r['write_bytes_per_launch'] / 1e9, r['avg_ns_kernel_trace'] / 1e6))
