@@ -35,6 +35,7 @@ struct RowRegs {
 
 typedef const unsigned __attribute__((address_space(1))) *gc_u32p;     // global (not flat) loads
 typedef unsigned __attribute__((address_space(1))) *g_u32p;
+typedef uint8_t __attribute__((address_space(1))) *g_u8p;              // global (not flat) byte stores: a flat access also counts on lgkmcnt
 
 // Unconditional loads from a row clamped into the image: no exec-masked load blocks (hipcc puts an
 // `s_waitcnt vmcnt(0)` behind every predicated load, one exposed memory round trip each).  Whether
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
                 const int nbytes = (w - x0) * C;
 #pragma unroll
                 for (int j = 0; j < P * C; j++)
-                    if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+                    if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
             }
         }
 #pragma unroll
@@ -485,8 +486,33 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
     for (int q = 0; q < ND; q++) o_leave[q] = 0;
 
+    // A row's result is stored at the TOP of the next iteration (it lives in `prev` anyway), behind a barrier that
+    // makes the compiler wait for this row's prefetched loads first: vmcnt retires in order, so with the store issued
+    // at the end of the row the wait for the next row's loads also waited for the store's write acknowledgement -- a
+    // memory round trip in the serial chain of every row.
+    auto store_row = [&](int yy, const unsigned (&res)[ND]) {
+        if (!act) return;
+        uint8_t *o = out + (size_t)yy * opitch + (size_t)x0 * C;
+        if (x0 + P <= w) {
+#pragma unroll
+            for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+        } else {
+            const int nbytes = (w - x0) * C;
+#pragma unroll
+            for (int j = 0; j < P * C; j++)
+                if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+        }
+    };
     for (int y = 0; y < h; y++) {
-        // ---- next row's loads first: independent of the serial chain ----
+        // ---- this row's inputs (loaded a row ago) have landed: only now the previous row's store and the next row's
+        // loads go out ----
+        {
+#pragma unroll
+            for (int q = 0; q < P / 4; q++) asm volatile("" : "+v"(r_enter.m[q]), "+v"(r_leave.m[q]), "+v"(r_cur.m[q]) : : "memory");
+#pragma unroll
+            for (int q = 0; q < ND; q++) asm volatile("" : "+v"(r_enter.px[q]), "+v"(r_leave.px[q]), "+v"(r_cur.px[q]), "+v"(o_leave[q]) : : "memory");
+        }
+        if (y >= 1) store_row(y - 1, prev);
         const int yn = y + 1;
         RowRegs<C, P> n_enter = load_row(yn + n - 1, x0);
         RowRegs<C, P> n_leave = load_row(yn - n - 1, x0);
@@ -634,18 +660,6 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 res[0] = ((r_cur.px[0] & on) | (qd[0] & ~on)) & pxm[0];
             }
         }
-        if (act) {
-            uint8_t *o = out + (size_t)y * opitch + (size_t)x0 * C;
-            if (x0 + P <= w) {
-#pragma unroll
-                for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
-            } else {
-                const int nbytes = (w - x0) * C;
-#pragma unroll
-                for (int j = 0; j < P * C; j++)
-                    if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
-            }
-        }
 #pragma unroll
         for (int q = 0; q < ND; q++) prev[q] = res[q];
         if constexpr (!DB) lds_barrier();   // everyone is done reading the LDS rows (DB: the next row uses the other buffer)
@@ -654,6 +668,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
         for (int q = 0; q < ND; q++) o_leave[q] = n_oleave[q];
     }
+    if (h >= 1) store_row(h - 1, prev);
 }
 
 // Rows of 4097..8160 columns: the same packed scheme with TWO groups of 4 columns per thread (columns
@@ -891,7 +906,7 @@ __device__ __forceinline__ void optimise_packed_wide_rows(const OptJob &J, unsig
                     const int nbytes = (w - xg) * C;
 #pragma unroll
                     for (int j = 0; j < P * C; j++)
-                        if (j < nbytes) o[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+                        if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
                 }
             }
 #pragma unroll
