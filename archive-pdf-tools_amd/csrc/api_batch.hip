@@ -642,7 +642,7 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
     const CtrlLayout L(b->n, b->nb_cap);
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
-        if (!b->layer[Lr].pl.p) TRY(b->layer[Lr].alloc(ctx, N, w * c, h));
+        if (!b->layer[Lr].pl.p) TRY(b->layer[Lr].alloc(ctx, b->n, w * c, h));      // capacity, not the pages in use
         TRY(prepare_thumb(b, Lr, Lr == 0 ? fg_ds : bg_ds, Lr == 0 ? too_small_fg : too_small_bg));
     }
     OptJob *hj = reinterpret_cast<OptJob *>(b->hctrl + L.optjobs);

@@ -106,6 +106,11 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
     auto eidx = [&](int col) { const int e = col + npad; return (e + e / P) * EW; };
 
     const bool act = x0 < w;                       // thread has at least one real column
+    // Threads past the image (the thread count is rounded up, P columns each) still issue their unconditional row
+    // loads; they read the last column group that starts inside the image instead of P*C*(x0 - w) bytes past the row
+    // -- which for the last rows of a small image lies beyond the allocation (fault found by tests/fuzz_parity.py).
+    // Their bytes are masked out where they are used.
+    const int xl = min(x0, max(0, ((w - 1) / P) * P));
     unsigned colok = 0;                            // bit i: column x0+i < w
 #pragma unroll
     for (int i = 0; i < P; i++) if (x0 + i < w) colok |= 1u << i;
@@ -178,12 +183,12 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
 
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0);
+        RowRegs<C, P> r = load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, xl);
         fir_apply(r, +1);
     }
-    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, h, x0);
-    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
-    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, x0);
+    RowRegs<C, P> r_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, n - 1, h, xl);
+    RowRegs<C, P> r_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, xl);
+    RowRegs<C, P> r_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, 0, h, xl);
     unsigned o_leave[P * C / 4];
 #pragma unroll
     for (int i = 0; i < P * C / 4; i++) o_leave[i] = 0;
@@ -191,12 +196,12 @@ __global__ __launch_bounds__(MAXT) void optimise_kernel(const OptJob *jobs) {
     for (int y = 0; y < h; y++) {
         // ---- issue next row's loads first (independent of the serial chain) ----
         const int yn = y + 1;
-        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, h, x0);
-        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, h, x0);
-        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, h, x0);
+        RowRegs<C, P> n_enter = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn + n - 1, h, xl);
+        RowRegs<C, P> n_leave = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn - n - 1, h, xl);
+        RowRegs<C, P> n_cur = load_row_regs<C, P>(mask, mpitch, img, ipitch, yn, h, xl);
         unsigned n_oleave[P * C / 4];
         {
-            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)x0 * C);
+            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)xl * C);
 #pragma unroll
             for (int i = 0; i < P * C / 4; i++) n_oleave[i] = p[i];
         }
@@ -714,13 +719,14 @@ __device__ __forceinline__ void optimise_packed_wide_rows(const OptJob &J, unsig
         else e.d[0] = p[0];
         return e;
     };
-    int x0[G];
+    int x0[G], xl[G];          // xl: column the unconditional row loads use (clamped into the image, see optimise_kernel)
     unsigned colm[G], pxm[G][ND];
     Ent firE[G][P], iirE[G][P];
     unsigned prev[G][ND];
 #pragma unroll
     for (int g = 0; g < G; g++) {
         x0[g] = (t + g * T) * P;
+        xl[g] = min(x0[g], max(0, ((w - 1) / P) * P));
         colm[g] = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) if (x0[g] + b < w) colm[g] |= 0xffu << (8 * b);
@@ -780,7 +786,7 @@ __device__ __forceinline__ void optimise_packed_wide_rows(const OptJob &J, unsig
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++)
 #pragma unroll
-        for (int g = 0; g < G; g++) fir_apply(g, load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, x0[g]), true);
+        for (int g = 0; g < G; g++) fir_apply(g, load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, xl[g]), true);
 
     for (int y = 0; y < h; y++) {
         RowRegs<C, P> r_cur[G];
@@ -790,10 +796,10 @@ __device__ __forceinline__ void optimise_packed_wide_rows(const OptJob &J, unsig
             unsigned o_leave[G][ND];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                r_enter[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y + n - 1, h, x0[g]);
-                r_leave[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y - n - 1, h, x0[g]);
-                r_cur[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y, h, x0[g]);
-                gc_u32p p = (gc_u32p)(out + (size_t)min(max(y - n - 1, 0), h - 1) * opitch + (size_t)x0[g] * C);
+                r_enter[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y + n - 1, h, xl[g]);
+                r_leave[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y - n - 1, h, xl[g]);
+                r_cur[g] = load_row_regs<C, P>(mask, mpitch, img, ipitch, y, h, xl[g]);
+                gc_u32p p = (gc_u32p)(out + (size_t)min(max(y - n - 1, 0), h - 1) * opitch + (size_t)xl[g] * C);
 #pragma unroll
                 for (int q = 0; q < ND; q++) o_leave[g][q] = p[q];
             }

@@ -36,6 +36,18 @@ def rnd_img(h, w, c=1):
     return np.clip(a, 0, 255).astype(np.uint8)
 
 
+if os.environ.get('FUZZ_TRACE'):        # wait for the stream after every batch call and say so: a device fault then names its stage
+    for _name in ('upload', 'set_boxes', 'set_count', 'mask_begin', 'sigmas', 'mask_finish', 'layers', 'download_mask',
+                  'download_mask_packed', 'download_layer'):
+        def _wrap(fn, name=_name):
+            def f(self, *a, **k):
+                r = fn(self, *a, **k)
+                _lib.check(self.lib.mrchip_batch_sync(self._h), 'sync')
+                print('ok', name, self.n, self.w, self.h, self.c, a[0] if a and isinstance(a[0], int) else '', flush=True)
+                return r
+            return f
+        setattr(mrc.Batch, _name, _wrap(getattr(mrc.Batch, _name)))
+
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 _last = open(os.path.join(ROOT, 'gpurun_out', 'fuzz_last_%d.txt' % seed), 'w')
 
@@ -46,7 +58,7 @@ def note(*a):
 
 
 while time.time() - t0 < budget:
-    what = rng.randint(12)
+    what = rng.randint(14)
     if what == 0:       # sauvola
         h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
         ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
@@ -182,6 +194,49 @@ while time.time() - t0 < budget:
                 b = next(e)
                 assert a.shape == b.shape and np.array_equal(a, b), ('batch', h, w, c, kw)
         tick('batch')
+    elif what == 12:    # stream of pages of mixed sizes / modes, short last batches, both mask formats
+        shapes = [(int(rng.randint(40, 400)), int(rng.randint(40, 700)), int(rng.choice([1, 3]))) for _ in range(int(rng.randint(1, 3)))]
+        npg = int(rng.randint(1, 9))
+        pages, spec = [], []
+        for i in range(npg):
+            h, w, c = shapes[int(rng.randint(len(shapes)))]
+            spec.append(dict(w=w, h=h, channels=c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 5, 11])),
+                             line_div=int(rng.choice([6, 12]))))
+            pages.append(synth.synth_page(**spec[-1]))
+        kw = dict(dpi=rng.choice([None, 200]), bg_downsample=rng.choice([None, 3]), fg_downsample=rng.choice([None, 2]))
+        kw = {k: (None if v is None else int(v)) for k, v in kw.items()}
+        fmt = str(rng.choice(['bool', 'packed'])); bp = int(rng.randint(1, 5))
+        note('stream', spec, kw, fmt, bp)
+        n = 0
+        for (img, hocr), (mask, fg, bg) in zip(pages, mrc.decompose_stream(iter(pages), batch_pages=bp, mask_format=fmt, copy=True, **kw)):
+            e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            em = next(e)
+            if fmt == 'packed': em = np.packbits(em, axis=1)
+            assert np.array_equal(mask, em), ('stream mask', n, kw, fmt)
+            for a in (fg, bg):
+                b = next(e)
+                assert a.shape == b.shape and np.array_equal(a, b), ('stream layer', n, kw)
+            n += 1
+        assert n == npg
+        tick('stream')
+    elif what == 13:    # create_threshold_mask: estimate + blur + Sauvola + in-place OR
+        h, w = int(rng.randint(8, 500)), int(rng.randint(8, 900))
+        gimg, _ = synth.synth_page(max(w, 64), max(h, 64), 1, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 8, 20])),
+                                   line_div=int(rng.choice([8, 16])))
+        gimg = np.ascontiguousarray(gimg[:h, :w])
+        dpi = None if rng.rand() < 0.5 else int(rng.choice([100, 200, 400]))
+        m0 = rng.rand(h, w) < 0.05
+        note('threshold_mask', h, w, dpi)
+        got = m0.copy()
+        mrc.create_threshold_mask(got, gimg.astype(np.float32), dpi=dpi)
+        sig = O.estimate_noise(gimg.astype(np.float32))
+        src = gimg
+        if sig > 1.0:
+            wts, _r = mrc.gaussian_weights(sig * 0.1)
+            src = O.gaussian_filter(gimg.astype(np.float32), sig * 0.1, weights=wts).astype(np.uint8)
+        exp = m0 | O.threshold_image(src, dpi)
+        assert np.array_equal(got, exp), ('threshold_mask', h, w, dpi)
+        tick('threshold_mask')
     else:               # whole pages
         h, w = int(rng.randint(20, 900)), int(rng.randint(20, 1300)); c = int(rng.choice([1, 3]))
         img, hocr = synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 6, 12, 25])),

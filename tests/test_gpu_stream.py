@@ -82,3 +82,24 @@ def test_stream_rejects_bad_options_and_closes_on_abandon():
     m, fg, bg = next(mrc.decompose_stream([(img, hocr)], batch_pages=8))      # one page in a batch sized for 8
     em, ef, eb = _expect(img, hocr)
     assert np.array_equal(m, em) and np.array_equal(fg, ef) and np.array_equal(bg, eb)
+
+
+def test_one_batch_object_serves_growing_page_counts():
+    """regression (found by tests/fuzz_parity.py): a batch sized for 3 pages first used with 1 page, then with 2, then 3:
+    the layer planes are allocated for the capacity, not for the pages in use at first call"""
+    ctx = _lib.default_context()
+    pages = [synth.synth_page(658, 222, 3, seed=500 + i, noise_sigma=[0.0, 11.0, 5.0][i], line_div=12) for i in range(3)]
+    bt = mrc.Batch(ctx, 3, 658, 222, 3)
+    for sel in ([0], [1, 2], [0, 1, 2], [2]):
+        for j, i in enumerate(sel):
+            bt.upload(j, pages[i][0])
+            bt.set_boxes(j, mrc.hocr_boxes(pages[i][1], 658, 222))
+        bt.set_count(len(sel))
+        bt.mask_begin(51)
+        bt.mask_finish(bt.sigmas(), True)
+        fgs, bgs, _ = bt.layers(None, 3)
+        for j, i in enumerate(sel):
+            em, ef, eb = _expect(pages[i][0], pages[i][1], bg_downsample=3)
+            assert np.array_equal(bt.download_mask(j), em)
+            assert np.array_equal(bt.download_layer(j, 0, fgs), ef) and np.array_equal(bt.download_layer(j, 1, bgs), eb)
+    bt.close()
