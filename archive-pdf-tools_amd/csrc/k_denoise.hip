@@ -24,6 +24,8 @@
 // General (n, mincnt): byte-domain Jacobi sweeps to the same unique fixpoint.
 //
 // Algorithmic bytes: 2*w*h per call.
+#include <cstdlib>
+
 #include "mrchip_internal.h"
 
 namespace mrchip {
@@ -276,6 +278,169 @@ __global__ __launch_bounds__(64) void denoise_seq_kernel(unsigned *bits, int wpr
     }
 }
 
+// ---- the same solve, bands of rows in parallel ------------------------------------------------------------
+// Rows are sequential because row y needs the FINAL rows y-1, y-2.  But the final rows differ from the original
+// ones only where a pixel was dropped, and a dropped pixel matters to the rows below only if a pixel there sits on
+// the threshold: a band of rows solved from the ORIGINAL two rows above it is almost always right, and where it
+// is not, the error dies out after a few rows.  So: (1) every band of DN_BAND rows is solved by its own wave from
+// the originals above it (out of place: originals in `org`, results in `fin`); (2) one wave per page walks the band
+// boundaries top to bottom: where the true final rows above a band differ from the originals the band assumed, it
+// re-solves the band's rows from the true ones until two consecutive rows come out as they already were -- from
+// there on everything is identical, because a row depends on nothing but the two finals above it and originals.
+// The result is exactly the sequential one (the reconciliation is itself sequential, just short).
+constexpr int DN_BAND = 96;
+
+template <int KW>
+struct RowSolver {
+    const unsigned *org;
+    int wpr, h, lane;
+    unsigned inner[KW];
+    Row<KW> m0, m1, m2;
+    Sat hf2[KW], hf1[KW], hm1[KW], hm2[KW];
+
+    __device__ __forceinline__ void init(const unsigned *org_, int wpr_, int w, int h_, int lane_) {
+        org = org_; wpr = wpr_; h = h_; lane = lane_;
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            const int x0 = (lane * KW + k) * 32;
+            unsigned m = 0;
+            for (int i = 0; i < 32; i++) {
+                const int x = x0 + i;
+                if (x >= 2 && x < w - 2) m |= 1u << i;
+            }
+            inner[k] = m;
+        }
+    }
+    // ready to solve row y: f2 / f1 = final rows y-2, y-1
+    __device__ __forceinline__ void start(int y, const Row<KW> &f2, const Row<KW> &f1) {
+        m0 = load_row<KW>(org, wpr, y, h, lane);
+        m1 = load_row<KW>(org, wpr, y + 1, h, lane);
+        m2 = load_row<KW>(org, wpr, y + 2, h, lane);
+        h5<KW>(f2, lane, hf2);
+        h5<KW>(f1, lane, hf1);
+        h5<KW>(m1, lane, hm1);
+        h5<KW>(m2, lane, hm2);
+    }
+    // final row y (the row `start` / the previous `step` prepared), then advance to row y + 1; `next2` = original row y + 3
+    __device__ __forceinline__ Row<KW> step(const Row<KW> &next2) {
+        unsigned always[KW], t1[KW], t2[KW], fixed[KW], upd[KW];
+        {
+            unsigned L[KW], R[KW];
+            neighbours<KW>(m0, lane, L, R);
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                Sat s = sat_add(sat_add(hf2[k], hf1[k]), sat_add(hm1[k], hm2[k]));
+                unsigned d = sh_p1(m0.w[k], R[k]), e = sh_p2(m0.w[k], R[k]);
+                Sat rr; rr.b0 = d ^ e; rr.b1 = d & e; rr.hi = 0;
+                s = sat_add(s, rr);
+                always[k] = s.hi;
+                t1[k] = ~s.hi & s.b1 & s.b0;
+                t2[k] = ~s.hi & s.b1 & ~s.b0;
+                upd[k] = m0.w[k] & inner[k];
+                fixed[k] = m0.w[k] & ~inner[k];
+            }
+        }
+        Row<KW> f = m0;
+        for (;;) {
+            unsigned up = __shfl_up(f.w[KW - 1], 1);
+            if (lane == 0) up = 0;
+            unsigned changed = 0;
+            Row<KW> g;
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                unsigned Lw = k > 0 ? f.w[k - 1] : up;
+                unsigned a = sh_m1(f.w[k], Lw), b = sh_m2(f.w[k], Lw);
+                unsigned nf = fixed[k] | (upd[k] & (always[k] | (t1[k] & (a | b)) | (t2[k] & a & b)));
+                changed |= nf ^ f.w[k];
+                g.w[k] = nf;
+            }
+            f = g;
+            if (!__any(changed != 0)) break;
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) { hf2[k] = hf1[k]; hm1[k] = hm2[k]; }
+        h5<KW>(f, lane, hf1);
+        m0 = m1; m1 = m2; m2 = next2;
+        h5<KW>(m2, lane, hm2);
+        return f;
+    }
+};
+
+template <int KW>
+__device__ __forceinline__ void store_row(unsigned *fin, int wpr, int y, int lane, const Row<KW> &f) {
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+        const int j = lane * KW + k;
+        if (j < wpr) fin[(size_t)y * wpr + j] = f.w[k];
+    }
+}
+
+template <int KW>
+__device__ __forceinline__ bool rows_equal(const Row<KW> &a, const Row<KW> &b) {
+    unsigned d = 0;
+#pragma unroll
+    for (int k = 0; k < KW; k++) d |= a.w[k] ^ b.w[k];
+    return !__any(d != 0);
+}
+
+// grid (bands, pages); per page: fin = bits, org = bits + wpr * h
+template <int KW>
+__global__ __launch_bounds__(64) void denoise_band_kernel(unsigned *bits, int wpr, size_t bstride, int w, int h) {
+    const int lane = threadIdx.x;
+    unsigned *fin = bits + (size_t)blockIdx.y * bstride;
+    const unsigned *org = fin + (size_t)wpr * h;
+    const int y0 = max(2, (int)blockIdx.x * DN_BAND), y1 = min(h - 2, ((int)blockIdx.x + 1) * DN_BAND);
+    if (blockIdx.x == 0) {                 // rows outside the inner rectangle keep the original
+        store_row<KW>(fin, wpr, 0, lane, load_row<KW>(org, wpr, 0, h, lane));
+        store_row<KW>(fin, wpr, 1, lane, load_row<KW>(org, wpr, 1, h, lane));
+        store_row<KW>(fin, wpr, h - 2, lane, load_row<KW>(org, wpr, h - 2, h, lane));
+        store_row<KW>(fin, wpr, h - 1, lane, load_row<KW>(org, wpr, h - 1, h, lane));
+    }
+    if (y0 >= y1) return;
+    RowSolver<KW> S;
+    S.init(org, wpr, w, h, lane);
+    // the two rows above: originals (exact for the first band, whose rows 0, 1 are final as they are)
+    S.start(y0, load_row<KW>(org, wpr, y0 - 2, h, lane), load_row<KW>(org, wpr, y0 - 1, h, lane));
+    constexpr int PF = 4;
+    Row<KW> pf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) pf[i] = load_row<KW>(org, wpr, y0 + 3 + i, h, lane);
+    for (int y = y0; y < y1; y++) {
+        const Row<KW> f = S.step(pf[0]);
+        store_row<KW>(fin, wpr, y, lane, f);
+#pragma unroll
+        for (int i = 0; i + 1 < PF; i++) pf[i] = pf[i + 1];
+        pf[PF - 1] = load_row<KW>(org, wpr, y + 3 + PF, h, lane);
+    }
+}
+
+// one wave per page: reconcile the band boundaries in order
+template <int KW>
+__global__ __launch_bounds__(64) void denoise_fix_kernel(unsigned *bits, int wpr, size_t bstride, int w, int h) {
+    const int lane = threadIdx.x;
+    unsigned *fin = bits + (size_t)blockIdx.x * bstride;
+    const unsigned *org = fin + (size_t)wpr * h;
+    RowSolver<KW> S;
+    S.init(org, wpr, w, h, lane);
+    for (int yb = DN_BAND; yb < h - 2; yb += DN_BAND) {
+        const Row<KW> t2 = load_row<KW>(fin, wpr, yb - 2, h, lane), t1 = load_row<KW>(fin, wpr, yb - 1, h, lane);
+        if (rows_equal<KW>(t2, load_row<KW>(org, wpr, yb - 2, h, lane)) &&
+            rows_equal<KW>(t1, load_row<KW>(org, wpr, yb - 1, h, lane)))
+            continue;                       // the band below assumed exactly these rows
+        S.start(yb, t2, t1);
+        int same = 0;
+        for (int y = yb; y < h - 2; y++) {
+            const Row<KW> f = S.step(load_row<KW>(org, wpr, y + 3, h, lane));
+            if (rows_equal<KW>(f, load_row<KW>(fin, wpr, y, h, lane))) {
+                if (++same == 2) break;      // two rows in a row as they were: the rest of the page is unchanged
+            } else {
+                same = 0;
+                store_row<KW>(fin, wpr, y, lane, f);
+            }
+        }
+    }
+}
+
 // ---- general (n, mincnt): byte-domain Jacobi to the unique fixpoint ------------
 __global__ __launch_bounds__(256) void denoise_jacobi_kernel(const uint8_t *orig, const uint8_t *cur, uint8_t *next,
                                                              int pitch, int w, int h, int mincnt, int n,
@@ -301,14 +466,26 @@ __global__ __launch_bounds__(256) void denoise_jacobi_kernel(const uint8_t *orig
     next[idx] = v;
 }
 
+// per page: [final bit rows | original bit rows]; the final rows come first so that `bits + page * stride` is the
+// finished mask for the consumers (optimise reads it, unpack turns it into bytes)
 template <int KW>
 static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, size_t bstride, int w, int h, int npages) {
+    static const int one_wave = getenv("MRCHIP_DENOISE_SEQ") ? 1 : 0;      // A/B knob: the one-wave-per-page solve
+    if (one_wave) {
+        HIP_TRY(hipMemcpy2DAsync(bits, bstride * 4, bits + (size_t)wpr * h, bstride * 4, (size_t)wpr * h * 4, npages,
+                                 hipMemcpyDeviceToDevice, s));
+        LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8 * npages,
+               hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
+        return 0;
+    }
     LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8 * npages,
-           hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
+           hipLaunchKernelGGL((denoise_band_kernel<KW>), dim3(cdiv(h, DN_BAND), npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
+    LAUNCH(ctx, s, "denoise_reconcile", 0.0,
+           hipLaunchKernelGGL((denoise_fix_kernel<KW>), dim3(npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
     return 0;
 }
 
-size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) + 256; }
+size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) * 2 + 256; }
 
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
                          size_t bits_stride, int npages) {
@@ -319,8 +496,8 @@ int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int 
     if (n == 2 && mincnt == 4 && wpr <= 64 * 8) {
         dim3 grid(cdiv(wpr, 256), h, npages);
         LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h * npages,
-               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask.p, pitch, mask.stride, w, h, bits, wpr,
-                                  bits_stride));
+               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask.p, pitch, mask.stride, w, h,
+                                  bits + (size_t)wpr * h, wpr, bits_stride));        // originals: second half of a page's scratch
         if (wpr <= 64) TRY(launch_seq<1>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, bits_stride, w, h, npages));

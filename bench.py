@@ -53,7 +53,7 @@ CONFIGS = {
                    w=3300, h=4600, c=1, dpi=None, bg=None, fg=None, pages=64, inflight=1, distinct=8, line_div=60,
                    seeds=list(range(303, 311)), digests='c3_gray_pages', metric='Sauvola HBM GB/s (64 x 3300x4600 gray)'),
     'c5': dict(label='configs[4]: 8000x6000 RGB + hOCR, dpi=364 (window 91), fg and bg downsample 4',
-               w=8000, h=6000, c=3, dpi=364, bg=4, fg=4, pages=32, inflight=2, distinct=2, line_div=60,
+               w=8000, h=6000, c=3, dpi=364, bg=4, fg=4, pages=128, inflight=2, distinct=2, line_div=60,
                seeds=[505, 506], digests=None, metric='pages/sec MRC decompose (8000x6000 RGB)'),
 }
 STACK_PAGES = 512            # BASELINE.json configs[3]: the 512-page stack, sharded page i -> rank i mod N
