@@ -352,6 +352,24 @@ def main():
         st = stack_check(ctx, comm, mrc, synth, cfg, rank, world)
         if rank == 0:
             extra['config4_stack'] = st
+    if rank == 0 and not a.no_extras and not sauvola_only:
+        # single-page latency of the drop-in generator: one page, host arrays in and out
+        img, hocr, _ = host_pages[0]
+        lat = []
+        ctx.prof_enable(True)
+        for rep in range(4):
+            if rep == 1:
+                ctx.prof_reset()
+            t1 = time.perf_counter()
+            for _ in mrc.create_mrc_hocr_components(img, hocr, dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
+                                                    denoise_mask='fast', ctx=ctx):
+                pass
+            lat.append(time.perf_counter() - t1)
+        pr = ctx.prof_report()
+        ctx.prof_enable(False)
+        extra['single_page'] = {'latency_ms': round(min(lat[1:]) * 1e3, 2), 'pages_per_s': round(1.0 / min(lat[1:]), 1),
+                                'kernel_ms': {k: round(v['ms'] / 3, 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1]['ms'])[:8]},
+                                'what': 'mrc.create_mrc_hocr_components on one page, three yields, pageable host arrays in and out'}
     if rank == 0 and not a.no_extras:
         # measured ceiling to read the roofline fractions against: D2D copy, read + write bytes
         extra['hbm_copy_GBps_measured'] = round(ctx.hbm_copy_bandwidth(1 << 30, 10), 1)
