@@ -50,6 +50,7 @@ struct mrchip_batch {
     DevBuf gtmp;  int gtmp_pitch = 0;  size_t gtmp_stride = 0;     // float32 scratch of the blur
     DevBuf sig_scratch;  size_t sig_stride = 0;
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
+    OptMail opt_mail;                 // hand-off granules of optimise's column-strip schedule
     std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
     hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
     int bits_valid = 0;                       // dn_bits holds the finished masks at 1 bpp (fast denoise ran)
@@ -664,7 +665,7 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
         }
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(OptJob), hipMemcpyHostToDevice, s));
-    TRY(launch_optimise_jobs(ctx, s, dj, nj, w, h, c, nmax));
+    TRY(launch_optimise_jobs(ctx, s, dj, nj, w, h, c, nmax, &b->opt_mail));
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
         if (b->layer_small[Lr])

@@ -126,7 +126,8 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     OptJob job = {m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, n_size, invert_mask ? 1 : 0};
     HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
-    TRY(launch_optimise_jobs(ctx, s, jb.as<OptJob>(), 1, w, h, channels, n_size));
+    OptMail mail;
+    TRY(launch_optimise_jobs(ctx, s, jb.as<OptJob>(), 1, w, h, channels, n_size, &mail));
     TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -23,6 +23,8 @@
 // Algorithmic bytes: (1 + 2C)*w*h per call (mask + img in, out).
 #include <cstdlib>
 
+#include <initializer_list>
+
 #include "mrchip_internal.h"
 
 namespace mrchip {
@@ -360,8 +362,41 @@ __device__ __forceinline__ unsigned add_dw1(unsigned a, unsigned b) {      // a 
 // every LDS access becomes `thread base + immediate offset`), or -1 for a run-time n.
 // DB: the two LDS rows are double-buffered (row y publishes into buffer y&1), which removes the
 // second barrier of a row; used when 2x the rows fit the 160 KiB of LDS.
-template <int C, int NH, int NCT, bool DB, bool MB>
-__device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem) {
+// ---- column strips of one page-layer on different workgroups -------------------------------------------------
+// The causal window of optimise looks LEFT and UP only: pixel (y, x) needs outputs of rows y-n .. y-1, columns
+// x-n .. x-1, never of its own row.  So a row can be cut into strips, one workgroup each, as long as the strip to the
+// right gets the n columns at its left boundary of every finished output row of its left-hand neighbour.  STRIP_HALO
+// columns of halo on both sides: halo threads build the vertical FIR sums of their columns like everybody else
+// (inputs only); the LEFT halo threads keep the vertical IIR sums of the neighbour's last columns, fed row by row
+// through a mailbox in global memory instead of their own results.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): per (page-layer, boundary, row) three 16-byte granules
+// {3 dwords of output bytes, tag}, written with ONE `sc0 sc1` (write-through) store each by the neighbour's last three
+// threads and read with `sc0 sc1` loads: no fence, no separate flag, valid wherever the two workgroups run.  The tag is
+// launch epoch << 16 | row, so nothing left in the buffer by an earlier launch can be mistaken for data.  The consumer
+// asks for row y's granules one row early; in the steady state the neighbour is a row or two ahead and the data is
+// there, otherwise it polls (bounded).  Left strips have the lower block index: they are dispatched first.
+constexpr int STRIP_HALO = 12;         // >= n for the packed kernels (n <= 11), a multiple of 4
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a register quad the inline asm can name
+struct StripInfo {
+    int S;                  // strips per page-layer (grid = jobs * S), 1 = whole rows
+    int sw;                 // core columns per strip (multiple of 4)
+    u32x4 *mail;            // [job][S-1][h][4] granules
+    unsigned tagbase;       // epoch << 16
+    unsigned *err;          // set when a poll gave up
+};
+
+__device__ __forceinline__ u32x4 mail_load(const u32x4 *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void mail_store(u32x4 *p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int C, int NH, int NCT, bool DB, bool MB, bool STRIP = false>
+__device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem, const StripInfo SI = StripInfo{1, 0, nullptr, 0, nullptr},
+                                                     int job_index = 0, int strip = 0) {
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
     constexpr int ND = P * C / 4;                 // dwords of pixel bytes per thread-row
@@ -381,8 +416,10 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int npad = n;
     const int T = blockDim.x;
     const int t = threadIdx.x;
-    const int x0 = t * P;
-    const int wr = min(T * P, (w + 3) & ~3);      // columns that get an entry
+    const int XS = STRIP ? strip * SI.sw : 0;                       // first core column of this workgroup
+    const int XE = STRIP ? min(w, XS + SI.sw) : w;                  // one past its last core column
+    const int x0 = STRIP ? XS - STRIP_HALO + t * P : t * P;         // absolute column of the thread (may be < 0 or >= w)
+    const int wr = STRIP ? T * P : min(T * P, (w + 3) & ~3);        // columns that get an LDS entry (thread-relative)
     const int nent = wr + 2 * npad;
     const int nelem = nent + nent / P + 1;
     unsigned *firA0 = reinterpret_cast<unsigned *>(smem);
@@ -396,16 +433,30 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int ebase = 5 * t * EW;
     auto eidx = [&](int col) { const int d = col - x0 + npad; return ebase + (d + (d >> 2)) * EW; };
 
-    const bool act = x0 < w;
+    const bool act = STRIP ? (x0 >= XS && x0 < XE) : (x0 < w);      // thread owns output columns
+    const bool lhalo = STRIP && strip > 0 && x0 < XS && x0 >= XS - STRIP_HALO;     // carries the neighbour's IIR columns
+    const bool producer = STRIP && strip + 1 < SI.S && x0 >= XS + SI.sw - STRIP_HALO && x0 < XS + SI.sw;
+    const int xl = min(max(x0, 0), max(0, ((w - 1) / P) * P));      // column the unconditional row loads use
     unsigned colm = 0, pxm[ND];                   // 0xFF per valid column / per valid pixel byte
 #pragma unroll
-    for (int b = 0; b < 4; b++) if (x0 + b < w) colm |= 0xffu << (8 * b);
+    for (int b = 0; b < 4; b++) if (x0 + b >= 0 && x0 + b < w) colm |= 0xffu << (8 * b);
 #pragma unroll
     for (int q = 0; q < ND; q++) {
         unsigned m = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) if (x0 + (4 * q + b) / C < w) m |= 0xffu << (8 * b);
+        for (int b = 0; b < 4; b++) { const int cc = x0 + (4 * q + b) / C; if (cc >= 0 && cc < w) m |= 0xffu << (8 * b); }
         pxm[q] = m;
+    }
+    // mailbox slots: what this thread writes (producer) / reads (left halo); other lanes point at a harmless slot
+    u32x4 *mail_out = nullptr;
+    const u32x4 *mail_in = nullptr;
+    if constexpr (STRIP) {
+        const size_t per_b = (size_t)h * 4;
+        u32x4 *base = SI.mail + (size_t)job_index * (SI.S - 1) * per_b;
+        const int lane_o = producer ? (x0 - (XS + SI.sw - STRIP_HALO)) / P : 3;
+        const int lane_i = lhalo ? (x0 - (XS - STRIP_HALO)) / P : 3;
+        mail_out = base + (size_t)min(strip, SI.S - 2) * per_b + lane_o;
+        mail_in = base + (size_t)max(strip - 1, 0) * per_b + lane_i;
     }
 
     struct Ent { unsigned d[EW]; };
@@ -481,12 +532,13 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 
     // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
     for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C, P> r = load_row(yy, x0);
+        RowRegs<C, P> r = load_row(yy, xl);
         fir_apply(r, true);
     }
-    RowRegs<C, P> r_enter = load_row(n - 1, x0);
-    RowRegs<C, P> r_leave = load_row(0, x0);
-    RowRegs<C, P> r_cur = load_row(0, x0);
+    RowRegs<C, P> r_enter = load_row(n - 1, xl);
+    RowRegs<C, P> r_leave = load_row(0, xl);
+    RowRegs<C, P> r_cur = load_row(0, xl);
+    u32x4 mb_prev = {0, 0, 0, 0}, mb_leave = {0, 0, 0, 0};      // STRIP: granules in flight
     unsigned o_leave[ND];
 #pragma unroll
     for (int q = 0; q < ND; q++) o_leave[q] = 0;
@@ -498,11 +550,11 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     auto store_row = [&](int yy, const unsigned (&res)[ND]) {
         if (!act) return;
         uint8_t *o = out + (size_t)yy * opitch + (size_t)x0 * C;
-        if (x0 + P <= w) {
+        if (x0 + P <= XE) {
 #pragma unroll
             for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
         } else {
-            const int nbytes = (w - x0) * C;
+            const int nbytes = (XE - x0) * C;
 #pragma unroll
             for (int j = 0; j < P * C; j++)
                 if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
@@ -516,15 +568,41 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             for (int q = 0; q < P / 4; q++) asm volatile("" : "+v"(r_enter.m[q]), "+v"(r_leave.m[q]), "+v"(r_cur.m[q]) : : "memory");
 #pragma unroll
             for (int q = 0; q < ND; q++) asm volatile("" : "+v"(r_enter.px[q]), "+v"(r_leave.px[q]), "+v"(r_cur.px[q]), "+v"(o_leave[q]) : : "memory");
+            if constexpr (STRIP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb_prev), "+v"(mb_leave) : : "memory");   // the granule loads are not the compiler's
         }
         if (y >= 1) store_row(y - 1, prev);
+        if constexpr (STRIP) {
+            if (t < 64 || producer) {              // wave 0 holds the left halo; the producers are the last three core threads
+                const unsigned tag_prev = SI.tagbase + (unsigned)(y - 1);
+                if (y >= 1 && producer)
+                    mail_store(mail_out + (size_t)(y - 1) * 4, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
+                if (y >= 1 && strip > 0 && t < 64) {
+                    // the neighbour's output row y-1 (asked for a row ago): poll until it is this launch's row y-1
+                    int spins = 0;
+                    while (__any(lhalo && mb_prev.w != tag_prev)) {
+                        __builtin_amdgcn_s_sleep(4);
+                        mb_prev = mail_load(mail_in + (size_t)(y - 1) * 4);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb_prev) : : "memory");
+                        if (++spins > (1 << 21)) { if (t == 0) *SI.err = 1u; break; }
+                    }
+                    if (lhalo) {
+                        prev[0] = mb_prev.x; if constexpr (ND > 1) prev[1] = mb_prev.y; if constexpr (ND > 2) prev[2] = mb_prev.z;
+                        o_leave[0] = mb_leave.x; if constexpr (ND > 1) o_leave[1] = mb_leave.y; if constexpr (ND > 2) o_leave[2] = mb_leave.z;
+                    }
+                }
+                if (strip > 0 && t < 64) {
+                    mb_prev = mail_load(mail_in + (size_t)min(y, h - 1) * 4);                       // prev of the next row
+                    mb_leave = mail_load(mail_in + (size_t)min(max(y - n, 0), h - 1) * 4);           // row (y+1)-n-1, seen before
+                }
+            }
+        }
         const int yn = y + 1;
-        RowRegs<C, P> n_enter = load_row(yn + n - 1, x0);
-        RowRegs<C, P> n_leave = load_row(yn - n - 1, x0);
-        RowRegs<C, P> n_cur = load_row(yn, x0);
+        RowRegs<C, P> n_enter = load_row(yn + n - 1, xl);
+        RowRegs<C, P> n_leave = load_row(yn - n - 1, xl);
+        RowRegs<C, P> n_cur = load_row(yn, xl);
         unsigned n_oleave[ND];
         {
-            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)x0 * C);
+            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)xl * C);
 #pragma unroll
             for (int q = 0; q < ND; q++) n_oleave[q] = p[q];
         }
@@ -554,7 +632,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             firA = firA0 + (size_t)(y & 1) * 2 * nelem * EW;
             iirA = firA + (size_t)nelem * EW;
         }
-        if (x0 < wr)
+        if (STRIP || x0 < wr)
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int e = eidx(x0 + i);
@@ -575,7 +653,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         unsigned qd[ND];
 #pragma unroll
         for (int q = 0; q < ND; q++) qd[q] = 0;
-        if (__any(on_cur != colm)) {
+        if (__any(act && on_cur != colm)) {
         // ---- horizontal windows of pixel x0: FIR [x0-n, x0+n) as NH packed halves, IIR [x0-n, x0) ----
         Ent aL, aR, aI;
 #pragma unroll
@@ -948,6 +1026,23 @@ __global__ __launch_bounds__(MAXT) void optimise_packed_kernel(const OptJob *job
     }
 }
 
+// grid = jobs * S workgroups: job = block / S, strip = block % S (left strips first)
+template <int C, int NH, int MAXT>
+__global__ __launch_bounds__(MAXT) void optimise_strip_kernel(const OptJob *jobs, StripInfo SI) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int job = blockIdx.x / SI.S, strip = blockIdx.x - job * SI.S;
+    const OptJob J = jobs[job];
+    if (J.mbits) {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, false, true, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, false, true, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, false, true, true>(J, smem, SI, job, strip);
+    } else {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, false, false, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, false, false, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, false, false, true>(J, smem, SI, job, strip);
+    }
+}
+
 // Self-test of the quotient both optimise kernels use: (unsigned)fma((float)v, rcp(cnt), rcp(cnt)/2) against
 // v / cnt for EVERY count the kernels can produce (1 .. 5120 = (2n)^2 + n^2 at n = 32) and every value
 // 0 .. 255*cnt (a window of cnt bytes): ~3.3e9 pairs.
@@ -989,9 +1084,74 @@ static int opt_geometry(int w, int c, int n, OptGeom *g) {
 
 // d_jobs: njobs OptJob records in device memory, all with the same w, c (same geometry);
 // n_max = the largest n_size among them (sizes the LDS rows)
-int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max) {
+// Column strips (optimise_strip_kernel) when whole rows would leave most of the chip idle -- few page-layers -- or do
+// not fit one workgroup (more than 4096 columns).  Returns 1 if it launched, 0 if the caller should go on, < 0 on error.
+static int try_strips(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max,
+                      OptMail *mail, double alg) {
+    const char *env = getenv("MRCHIP_OPT_STRIPS");          // 0: never, 128 / 256 / 512 / 1024: force that workgroup size
+    const int mode = env ? atoi(env) : -1;
+    if (!mail || mode == 0 || n_max > 11 || n_max < 1 || h >= 65536 || w < 64) return 0;
+    const int cus = ctx->cus > 0 ? ctx->cus : 256;
+    int T = 0;
+    if (mode > 0) T = mode;
+    else {
+        // the narrowest strips that still give every workgroup a CU of its own; rows of more than 4096 columns do not
+        // fit one workgroup of the packed kernel at all and always go in strips
+        if (njobs * 2 <= cus || w > 4096)
+            for (int cand : {128, 256, 512, 1024}) {
+                const int sw = 4 * (cand - 2 * STRIP_HALO / 4);
+                if ((long long)njobs * cdiv(w, sw) <= cus) { T = cand; break; }
+            }
+        if (T == 0 && w > 4096) T = 1024;
+    }
+    if (T == 0) return 0;
+    const int sw = 4 * (T - 2 * STRIP_HALO / 4);
+    const int S = cdiv(w, sw);
+    if (S < 2) return 0;
+    const size_t need = (size_t)njobs * (S - 1) * h * 4 * sizeof(u32x4) + 256;
+    if (need > mail->bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        TRY(mail->buf.alloc(ctx, need + need / 4));
+        mail->bytes = need + need / 4;
+        mail->epoch = 0;
+    }
+    if (mail->epoch == 0 || mail->epoch >= 0xfffe) {       // fresh buffer, or the 16-bit epoch is about to repeat
+        HIP_TRY(hipMemsetAsync(mail->buf.p, 0, mail->bytes, s));
+        mail->epoch = 0;
+    }
+    mail->epoch++;
+    StripInfo SI;
+    SI.S = S; SI.sw = sw; SI.mail = mail->buf.as<u32x4>() + 16;           // first 256 bytes: the error word
+    SI.tagbase = mail->epoch << 16; SI.err = mail->buf.as<unsigned>();
+    const int nent = T * 4 + 2 * n_max;
+    const size_t lds = (size_t)(nent + nent / 4 + 1) * ((c == 3) ? 16 : 8);
+    const char *nm = c == 3 ? "optimise_rgb" : "optimise_gray";
+#define OPT_STRIP(CC, NHH, MT)                                                                                   \
+    do {                                                                                                        \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_strip_kernel<CC, NHH, MT>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        LAUNCH(ctx, s, nm, alg,                                                                                 \
+               hipLaunchKernelGGL((optimise_strip_kernel<CC, NHH, MT>), dim3(njobs * S), dim3(T), lds, s, d_jobs, SI)); \
+    } while (0)
+    if (c == 3) {
+        if (n_max <= 8) { if (T <= 512) OPT_STRIP(3, 1, 512); else OPT_STRIP(3, 1, 1024); }
+        else { if (T <= 512) OPT_STRIP(3, 2, 512); else OPT_STRIP(3, 2, 1024); }
+    } else {
+        if (n_max <= 8) { if (T <= 512) OPT_STRIP(1, 1, 512); else OPT_STRIP(1, 1, 1024); }
+        else { if (T <= 512) OPT_STRIP(1, 2, 512); else OPT_STRIP(1, 2, 1024); }
+    }
+#undef OPT_STRIP
+    return 1;
+}
+
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max,
+                         OptMail *mail) {
     if (c != 1 && c != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
     if (w <= 0 || h <= 0 || njobs <= 0) return 0;
+    {
+        const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
+        if (st != 0) return st < 0 ? st : 0;
+    }
     OptGeom g;
     TRY(opt_geometry(w, c, n_max, &g));
     const double alg = (1.0 + 2.0 * c) * w * h * njobs;

@@ -211,7 +211,11 @@ struct OptJob {
     // the packed kernel reads it instead of the byte mask (an eighth of the traffic of 3 reads per row)
     const unsigned *mbits; int mwpr;
 };
-int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max);
+// hand-off buffer of the column-strip schedule (one per owner that may have a launch in flight: a batch, or a host-buffer
+// call); nullptr = whole rows only
+struct OptMail { DevBuf buf; size_t bytes = 0; unsigned epoch = 0; };
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max,
+                         OptMail *mail = nullptr);
 
 
 // hOCR: commit chosen thresholds into the mask in list order

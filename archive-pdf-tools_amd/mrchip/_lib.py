@@ -1,6 +1,7 @@
 """ctypes binding of libmrchip.so (include/mrchip.h)."""
 import ctypes as C
 import os
+import sys
 import threading
 import weakref
 
@@ -153,7 +154,8 @@ class Context:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():           # no HIP calls from interpreter shutdown: the runtime tears itself down
+                self.close()
         except Exception:
             pass
 
@@ -182,7 +184,8 @@ class Context:
 
         def _release(addr=p):
             _PINNED.pop(addr, None)
-            lib.mrchip_host_free(None, addr)      # hipHostFree needs no particular device
+            if not sys.is_finalizing():           # at interpreter exit the HIP runtime may already be shutting down:
+                lib.mrchip_host_free(None, addr)  # leave the pages to the OS (hipHostFree needs no particular device)
         weakref.finalize(buf, _release)
         return arr
 

@@ -234,7 +234,8 @@ class _Page:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
@@ -315,7 +316,8 @@ class Batch:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 

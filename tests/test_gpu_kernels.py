@@ -219,3 +219,25 @@ def test_optimise_quotient_equals_integer_division_exhaustively():
     bad = C.c_longlong(-1)
     _lib.check(_lib.load().mrchip_selftest_optimise_quotients(_lib.default_context().handle, C.byref(bad)))
     assert bad.value == 0
+
+
+def test_optimise_whole_rows_and_column_strips_agree_with_the_oracle(monkeypatch):
+    """optimise runs a page-layer either as one workgroup walking whole rows or as column strips on several workgroups
+    (the left boundary columns of every output row handed over through tagged write-through granules); small batches
+    take the strips by default.  Both schedules, every strip width, against the oracle."""
+    import mrc_oracle as O
+    from mrchip import optimiser
+    rng = np.random.RandomState(11)
+    cases = [(180, 1300, 3, 3, 0.1), (150, 1300, 3, 10, 0.9), (90, 4000, 3, 10, 0.92), (60, 8100, 3, 3, 0.08), (77, 1001, 1, 10, 0.5),
+             (64, 700, 3, 11, 0.5), (40, 5003, 1, 7, 0.3), (33, 129, 3, 3, 0.5), (12, 64, 1, 10, 1.0), (300, 2100, 3, 1, 0.0)]
+    for (h, w, c, n, dens) in cases:
+        img = rng.randint(0, 256, (h, w, c) if c == 3 else (h, w)).astype(np.uint8)
+        mask = (rng.rand(h, w) < dens).astype(np.uint8)
+        exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+        for mode in ('0', '128', '256', '512', '1024', None):
+            if mode is None:
+                monkeypatch.delenv('MRCHIP_OPT_STRIPS', raising=False)
+            else:
+                monkeypatch.setenv('MRCHIP_OPT_STRIPS', mode)
+            got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
+            assert np.array_equal(got, exp), ((h, w, c, n, dens), mode, int((got != exp).sum()))

@@ -23,7 +23,9 @@ def main():
     for combo in a.combos.split(','):
         bp, sl = (int(x) for x in combo.split('x'))
         pool = mrc.StreamPool(ctx)
+        ctx.prof_enable(True)
         for rep in range(2):
+            ctx.prof_reset()
             st = {}
             gen = mrc.decompose_stream(((made[i % 8][0], made[i % 8][1]) for i in range(a.pages)), bg_downsample=3,
                                        batch_pages=bp, slots=sl, mask_format=a.mask, pool=pool, stats=st)
@@ -32,6 +34,7 @@ def main():
             ctx.sync()
             dt = time.perf_counter() - t0
         print(json.dumps({'batch_pages': bp, 'slots': sl, 'pages_per_s': round(n / dt, 1), 'ms_per_page': round(dt / n * 1e3, 3),
+                          'optimise_ms': {k: round(v['ms'] / v['launches'], 3) for k, v in ctx.prof_report().items() if 'optimise' in k},
                           'phases': {k: round(v, 3) for k, v in st.items()}}))
         pool.close()
 
