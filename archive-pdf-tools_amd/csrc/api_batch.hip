@@ -796,6 +796,13 @@ MRCHIP_EXPORT int mrchip_page_layer(mrchip_page *pg, int is_bg, double downsampl
     if (too_small) *too_small = ts ? 1 : 0;
     return rc;
 }
+// both layers in ONE launch (fg and bg page-layers side by side on the chip): what the generator does at its second
+// yield -- the third then only downloads -- because one page alone is latency-bound per launch
+MRCHIP_EXPORT int mrchip_page_layers(mrchip_page *pg, double fg_downsample, double bg_downsample, int *fg_w, int *fg_h,
+                                     int *bg_w, int *bg_h, int *too_small) {
+    return mrchip_batch_layers(reinterpret_cast<mrchip_batch *>(pg), 3, fg_downsample, bg_downsample, fg_w, fg_h, bg_w, bg_h,
+                               too_small);
+}
 MRCHIP_EXPORT int mrchip_page_download_layer(mrchip_page *pg, int is_bg, uint8_t *out) {
     return mrchip_batch_download_layer(reinterpret_cast<mrchip_batch *>(pg), 0, is_bg, out);
 }

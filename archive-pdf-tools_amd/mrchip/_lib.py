@@ -57,6 +57,7 @@ SIGNATURES = {
     'mrchip_page_download_mask': (C.c_int, [vp, u8p]),
     'mrchip_page_download_mask_packed': (C.c_int, [vp, u8p]),
     'mrchip_page_layer': (C.c_int, [vp, C.c_int, C.c_double, intp, intp, intp]),
+    'mrchip_page_layers': (C.c_int, [vp, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
     'mrchip_page_download_layer': (C.c_int, [vp, C.c_int, u8p]),
     'mrchip_page_sync': (C.c_int, [vp]),
     'mrchip_page_box_decisions': (C.c_int, [vp, i32p, C.c_int]),

@@ -278,6 +278,13 @@ class _Page:
                                               C.byref(oh), C.byref(small)), 'mrchip_page_layer')
         return ow.value, oh.value, bool(small.value)
 
+    def layers(self, fg_downsample, bg_downsample):
+        """fg and bg in one launch: ((fg_w, fg_h), (bg_w, bg_h), too_small bits)"""
+        fw, fh, bw, bh, ts = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.lib.mrchip_page_layers(self._h, float(fg_downsample or 0.0), float(bg_downsample or 0.0), C.byref(fw),
+                                               C.byref(fh), C.byref(bw), C.byref(bh), C.byref(ts)), 'mrchip_page_layers')
+        return (fw.value, fh.value), (bw.value, bh.value), ts.value
+
     def download_layer(self, is_bg, ow, oh):
         shape = (oh, ow) if self.c == 1 else (oh, ow, 3)
         out = np.empty(shape, dtype=np.uint8)
@@ -723,9 +730,15 @@ def create_mrc_hocr_components(image, hocr_word_data,
             raise ValueError('Invalid denoise option:', denoise_mask)         # mrc.py:396
         yield mask_arr
 
+        sizes = None
         for is_bg, ds, key in ((0, fg_downsample, 'fg'), (1, bg_downsample, 'bg')):
             t = time()
-            ow, oh, too_small = page.layer(is_bg, ds)
+            if sizes is None:
+                # both layers are made when the first one is asked for, in one launch: a single page leaves the chip
+                # nearly idle, the two page-layers run side by side (a caller that stops after the mask, recode.py:400-408,
+                # never gets here)
+                sizes = page.layers(fg_downsample, bg_downsample)
+            (ow, oh), too_small = sizes[is_bg], bool(sizes[2] & (1 << is_bg))
             arr = page.download_layer(is_bg, ow, oh)
             now = time()
             if timing_data is not None:

@@ -154,6 +154,10 @@ int mrchip_page_download_mask_packed(mrchip_page *pg, uint8_t *packed);
  * *too_small = 1 reproduces 'too-small-to-downsample' (mrc.py:429-431). */
 int mrchip_page_layer(mrchip_page *pg, int is_bg, double downsample, int *out_w, int *out_h,
                       int *too_small);
+/* both layers in one launch (the generator's second yield: a single page is latency-bound per launch, so fg and bg run
+ * side by side; the third yield then only downloads).  too_small: bit 0 fg, bit 1 bg. */
+int mrchip_page_layers(mrchip_page *pg, double fg_downsample, double bg_downsample, int *fg_w, int *fg_h,
+                       int *bg_w, int *bg_h, int *too_small);
 int mrchip_page_download_layer(mrchip_page *pg, int is_bg, uint8_t *out);
 int mrchip_page_sync(mrchip_page *pg);
 /* decisions of the hOCR boxes after mask_finish (diagnostics / tests) */
