@@ -664,6 +664,16 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
             nmax = std::max(nmax, j.n);
         }
     }
+    if (const char *e = getenv("MRCHIP_OPT_ORDER")) {          // experiment: fg / bg jobs interleaved in blocks of `e`
+        const int blk = atoi(e);
+        if (blk > 0 && do_fg && do_bg && N % blk == 0) {
+            std::vector<OptJob> tmp(hj, hj + nj);
+            int k = 0;
+            for (int i0 = 0; i0 < N; i0 += blk)
+                for (int Lr = 0; Lr < 2; Lr++)
+                    for (int i = i0; i < i0 + blk; i++) hj[k++] = tmp[Lr * N + i];
+        }
+    }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(OptJob), hipMemcpyHostToDevice, s));
     TRY(launch_optimise_jobs(ctx, s, dj, nj, w, h, c, nmax, &b->opt_mail));
     for (int Lr = 0; Lr < 2; Lr++) {

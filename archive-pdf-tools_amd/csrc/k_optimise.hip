@@ -43,33 +43,42 @@ typedef uint8_t __attribute__((address_space(1))) *g_u8p;              // global
 // `s_waitcnt vmcnt(0)` behind every predicated load, one exposed memory round trip each).  Whether
 // the row / the columns count is decided where the bytes are USED (wave-uniform row tests, column
 // byte masks).  Columns >= w read the row's padding (or the next row), which the masks zero.
+// vo_m / vo_px: the lane's byte offsets into the mask row and the pixel row.  Callers that keep them opaque to the
+// optimiser inside their row loop (an empty asm) get `uniform row base + 32-bit lane offset` loads (SGPR-base
+// addressing); otherwise LICM hoists `img + lane offset` as a 64-bit per-lane pointer and every row pays 64-bit
+// vector multiply-adds for its addresses.
 template <int C, int P>
-__device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
-                                                       int y, int h, int x0) {
+__device__ __forceinline__ RowRegs<C, P> load_row_regs_at(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
+                                                          int y, int h, unsigned vo_m, unsigned vo_px) {
     RowRegs<C, P> r;
     const int yc = min(max(y, 0), h - 1);
-    gc_u32p pm = (gc_u32p)(mask + (size_t)yc * mpitch + x0);
-    gc_u32p pi = (gc_u32p)(img + (size_t)yc * ipitch + (size_t)x0 * C);
+    gc_u32p pm = (gc_u32p)((mask + (size_t)yc * mpitch) + vo_m);
+    gc_u32p pi = (gc_u32p)((img + (size_t)yc * ipitch) + vo_px);
 #pragma unroll
     for (int i = 0; i < P / 4; i++) r.m[i] = pm[i];
 #pragma unroll
     for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
     return r;
 }
+template <int C, int P>
+__device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int mpitch, const uint8_t *img, int ipitch,
+                                                       int y, int h, int x0) {
+    return load_row_regs_at<C, P>(mask, mpitch, img, ipitch, y, h, (unsigned)x0, (unsigned)(x0 * C));
+}
 
-// Same with the mask taken from 1-bpp rows: the lane's 4 columns are one nibble of a dword that 8 lanes share
+// Same with the mask taken from 1-bpp rows: the lane's 4 columns are one nibble of a dword that 8 lanes share; the raw
+// word is returned, the nibble is picked where the row is used
 template <int C, int P>
 __device__ __forceinline__ RowRegs<C, P> load_row_regs_bits(const unsigned *mbits, int mwpr, const uint8_t *img, int ipitch,
-                                                            int y, int h, int x0) {
+                                                            int y, int h, unsigned vo_m, unsigned vo_px) {
     static_assert(P == 4, "one nibble per lane");
     RowRegs<C, P> r;
     const int yc = min(max(y, 0), h - 1);
-    gc_u32p pm = (gc_u32p)(mbits + (size_t)yc * mwpr + (x0 >> 5));
-    gc_u32p pi = (gc_u32p)(img + (size_t)yc * ipitch + (size_t)x0 * C);
-    const unsigned word = pm[0];
+    gc_u32p pm = (gc_u32p)((const uint8_t *)(mbits + (size_t)yc * mwpr) + vo_m);
+    gc_u32p pi = (gc_u32p)((img + (size_t)yc * ipitch) + vo_px);
+    r.m[0] = pm[0];
 #pragma unroll
     for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
-    r.m[0] = (((word >> (x0 & 31)) & 0xFu) * 0x00204081u) & 0x01010101u;       // bit k -> byte k = 0/1
     return r;
 }
 
@@ -408,9 +417,10 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const unsigned invm = J.invert ? 0xffffffffu : 0u;
     const unsigned *mbits = J.mbits;
     const int mwpr = J.mwpr;
-    auto load_row = [&](int yy, int xx) {
-        if constexpr (MB) return load_row_regs_bits<C, P>(mbits, mwpr, img, ipitch, yy, h, xx);
-        else return load_row_regs<C, P>(mask, mpitch, img, ipitch, yy, h, xx);
+    unsigned vo_m = 0, vo_px = 0;          // lane offsets of the row loads, set below (kept opaque inside the row loop)
+    auto load_row = [&](int yy, int) {
+        if constexpr (MB) return load_row_regs_bits<C, P>(mbits, mwpr, img, ipitch, yy, h, vo_m, vo_px);
+        else return load_row_regs_at<C, P>(mask, mpitch, img, ipitch, yy, h, vo_m, vo_px);
     };
 
     const int npad = n;
@@ -437,6 +447,8 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const bool lhalo = STRIP && strip > 0 && x0 < XS && x0 >= XS - STRIP_HALO;     // carries the neighbour's IIR columns
     const bool producer = STRIP && strip + 1 < SI.S && x0 >= XS + SI.sw - STRIP_HALO && x0 < XS + SI.sw;
     const int xl = min(max(x0, 0), max(0, ((w - 1) / P) * P));      // column the unconditional row loads use
+    vo_px = (unsigned)(xl * C);
+    vo_m = MB ? (unsigned)((xl >> 5) * 4) : (unsigned)xl;
     unsigned colm = 0, pxm[ND];                   // 0xFF per valid column / per valid pixel byte
 #pragma unroll
     for (int b = 0; b < 4; b++) if (x0 + b >= 0 && x0 + b < w) colm |= 0xffu << (8 * b);
@@ -476,11 +488,22 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         return e;
     };
 
-    // 0xFF per selected column of a mask dword (nonzero byte, optional inversion, inside the image)
+    // 0xFF per selected column (mask set, optional inversion, inside the image).  MB: `m` is the raw 1-bpp word, the
+    // lane's 4 columns are one nibble of it: nibble -> (inversion, validity) -> one byte 0/1 per bit -> x 255
+    const unsigned msh = (unsigned)xl & 31u;
+    unsigned coln = 0;                             // bit i: column x0 + i is inside the image
+#pragma unroll
+    for (int b = 0; b < 4; b++) if (x0 + b >= 0 && x0 + b < w) coln |= 1u << b;
+    const unsigned invn = J.invert ? 0xFu : 0u;
     auto on_bytes = [&](unsigned m) {
-        unsigned tt = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;
-        tt = (tt - (tt >> 7)) | tt;
-        return (tt ^ invm) & colm;
+        if constexpr (MB) {
+            const unsigned nib = ((m >> msh) ^ invn) & coln;
+            return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u;       // (a full multiply: bit 24 is beyond __umul24)
+        } else {
+            unsigned tt = (((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;
+            tt = (tt - (tt >> 7)) | tt;
+            return (tt ^ invm) & colm;
+        }
     };
     // FIR entries of the 4 columns of a row: masked pixel bytes + selection bit
     auto fir_entries = [&](const RowRegs<C, P> &r, Ent (&e)[P]) {
@@ -535,13 +558,21 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         RowRegs<C, P> r = load_row(yy, xl);
         fir_apply(r, true);
     }
-    RowRegs<C, P> r_enter = load_row(n - 1, xl);
-    RowRegs<C, P> r_leave = load_row(0, xl);
-    RowRegs<C, P> r_cur = load_row(0, xl);
-    u32x4 mb_prev = {0, 0, 0, 0}, mb_leave = {0, 0, 0, 0};      // STRIP: granules in flight
-    unsigned o_leave[ND];
+    // The inputs of a row (entering / leaving / current image row, leaving output row, STRIP: the neighbour's granules)
+    // are loaded one row ahead.  Two sets of them alternate -- the row loop is unrolled by two, row y consumes one set
+    // while its loads for row y+1 fill the other -- so no register is copied from a "next" to a "current" variable.
+    struct RowSet {
+        RowRegs<C, P> e, l, c;
+        unsigned ol[ND];
+        u32x4 mbp, mbl;            // STRIP: granules in flight
+    };
+    RowSet SA, SB;
+    SA.e = load_row(n - 1, xl);
+    SA.l = load_row(0, xl);
+    SA.c = load_row(0, xl);
+    SA.mbp = u32x4{0, 0, 0, 0}; SA.mbl = u32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < ND; q++) o_leave[q] = 0;
+    for (int q = 0; q < ND; q++) SA.ol[q] = 0;
 
     // A row's result is stored at the TOP of the next iteration (it lives in `prev` anyway), behind a barrier that
     // makes the compiler wait for this row's prefetched loads first: vmcnt retires in order, so with the store issued
@@ -560,17 +591,26 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
         }
     };
-    for (int y = 0; y < h; y++) {
+    // count of causal output pixels in the window, (y - ys) * (x - xs), as a float per column: it only changes while
+    // the window is still growing (rows 0..n), so the steady state finds it in registers
+    float kf[P];
+    int dxw[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) { kf[i] = 0.0f; dxw[i] = (x0 + i) - max(0, x0 + i - n); }
+    auto do_row = [&](const int y, RowSet &RS, RowSet &NS) {
         // ---- this row's inputs (loaded a row ago) have landed: only now the previous row's store and the next row's
         // loads go out ----
         {
 #pragma unroll
-            for (int q = 0; q < P / 4; q++) asm volatile("" : "+v"(r_enter.m[q]), "+v"(r_leave.m[q]), "+v"(r_cur.m[q]) : : "memory");
+            for (int q = 0; q < P / 4; q++) asm volatile("" : "+v"(RS.e.m[q]), "+v"(RS.l.m[q]), "+v"(RS.c.m[q]) : : "memory");
 #pragma unroll
-            for (int q = 0; q < ND; q++) asm volatile("" : "+v"(r_enter.px[q]), "+v"(r_leave.px[q]), "+v"(r_cur.px[q]), "+v"(o_leave[q]) : : "memory");
-            if constexpr (STRIP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb_prev), "+v"(mb_leave) : : "memory");   // the granule loads are not the compiler's
+            for (int q = 0; q < ND; q++) asm volatile("" : "+v"(RS.e.px[q]), "+v"(RS.l.px[q]), "+v"(RS.c.px[q]), "+v"(RS.ol[q]) : : "memory");
         }
         if (y >= 1) store_row(y - 1, prev);
+        // STRIP: the next row's granules.  The loads are asm statements the compiler takes for finished: they stay in
+        // these locals, untouched, until the `s_waitcnt` at the bottom of this row, and only then move into the next
+        // row's set (a register copy between an asynchronous load and its wait would read the old contents)
+        u32x4 nmbp = {0, 0, 0, 0}, nmbl = {0, 0, 0, 0};
         if constexpr (STRIP) {
             if (t < 64 || producer) {              // wave 0 holds the left halo; the producers are the last three core threads
                 const unsigned tag_prev = SI.tagbase + (unsigned)(y - 1);
@@ -579,37 +619,37 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 if (y >= 1 && strip > 0 && t < 64) {
                     // the neighbour's output row y-1 (asked for a row ago): poll until it is this launch's row y-1
                     int spins = 0;
-                    while (__any(lhalo && mb_prev.w != tag_prev)) {
+                    while (__any(lhalo && RS.mbp.w != tag_prev)) {
                         __builtin_amdgcn_s_sleep(4);
-                        mb_prev = mail_load(mail_in + (size_t)(y - 1) * 4);
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb_prev) : : "memory");
+                        RS.mbp = mail_load(mail_in + (size_t)(y - 1) * 4);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(RS.mbp) : : "memory");
                         if (++spins > (1 << 21)) { if (t == 0) *SI.err = 1u; break; }
                     }
                     if (lhalo) {
-                        prev[0] = mb_prev.x; if constexpr (ND > 1) prev[1] = mb_prev.y; if constexpr (ND > 2) prev[2] = mb_prev.z;
-                        o_leave[0] = mb_leave.x; if constexpr (ND > 1) o_leave[1] = mb_leave.y; if constexpr (ND > 2) o_leave[2] = mb_leave.z;
+                        prev[0] = RS.mbp.x; if constexpr (ND > 1) prev[1] = RS.mbp.y; if constexpr (ND > 2) prev[2] = RS.mbp.z;
+                        RS.ol[0] = RS.mbl.x; if constexpr (ND > 1) RS.ol[1] = RS.mbl.y; if constexpr (ND > 2) RS.ol[2] = RS.mbl.z;
                     }
                 }
                 if (strip > 0 && t < 64) {
-                    mb_prev = mail_load(mail_in + (size_t)min(y, h - 1) * 4);                       // prev of the next row
-                    mb_leave = mail_load(mail_in + (size_t)min(max(y - n, 0), h - 1) * 4);           // row (y+1)-n-1, seen before
+                    nmbp = mail_load(mail_in + (size_t)min(y, h - 1) * 4);                       // prev of the next row
+                    nmbl = mail_load(mail_in + (size_t)min(max(y - n, 0), h - 1) * 4);           // row (y+1)-n-1, seen before
                 }
             }
         }
         const int yn = y + 1;
-        RowRegs<C, P> n_enter = load_row(yn + n - 1, xl);
-        RowRegs<C, P> n_leave = load_row(yn - n - 1, xl);
-        RowRegs<C, P> n_cur = load_row(yn, xl);
-        unsigned n_oleave[ND];
+        asm volatile("" : "+v"(vo_m), "+v"(vo_px));          // see load_row_regs_at
+        NS.e = load_row(yn + n - 1, xl);
+        NS.l = load_row(yn - n - 1, xl);
+        NS.c = load_row(yn, xl);
         {
-            gc_u32p p = (gc_u32p)(out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch + (size_t)xl * C);
+            gc_u32p p = (gc_u32p)((out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch) + vo_px);
 #pragma unroll
-            for (int q = 0; q < ND; q++) n_oleave[q] = p[q];
+            for (int q = 0; q < ND; q++) NS.ol[q] = p[q];
         }
 
         // ---- vertical running sums for row y (wave-uniform row tests) ----
-        if (y + n - 1 < h && n >= 1) fir_apply(r_enter, true);        // ye = min(h, y+n)
-        if (y - n - 1 >= 0 && n >= 1) fir_apply(r_leave, false);      // ys = max(0, y-n)
+        if (y + n - 1 < h && n >= 1) fir_apply(RS.e, true);        // ye = min(h, y+n)
+        if (y - n - 1 >= 0 && n >= 1) fir_apply(RS.l, false);      // ys = max(0, y-n)
         if (y >= 1 && n >= 1) {
             Ent e[P];
             iir_entries(prev, e);
@@ -619,13 +659,17 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         if (y - n - 1 >= 0 && n >= 1) {
             unsigned ol[ND];
 #pragma unroll
-            for (int q = 0; q < ND; q++) ol[q] = o_leave[q] & pxm[q];
+            for (int q = 0; q < ND; q++) ol[q] = RS.ol[q] & pxm[q];
             Ent e[P];
             iir_entries(ol, e);
 #pragma unroll
             for (int i = 0; i < P; i++) esub(iirE[i], e[i]);
         }
-        const int ys = max(0, y - n);
+        if (y <= n) {
+            asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
+#pragma unroll
+            for (int i = 0; i < P; i++) kf[i] = (float)(y * dxw[i]);          // y - ys = y while y <= n
+        }
 
         // ---- publish: the registers already hold the LDS entry format ----
         if constexpr (DB) {
@@ -649,7 +693,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         // Only pixels with mask==0 get a quotient.  When every pixel of this wave's 256 columns is masked
         // in this row (most of the bg layer: the inverted mask is set wherever there is no ink) the
         // horizontal windows and the divisions are skipped for the whole wave; the row is a copy.
-        const unsigned on_cur = on_bytes(r_cur.m[0]);
+        const unsigned on_cur = on_bytes(RS.c.m[0]);
         unsigned qd[ND];
 #pragma unroll
         for (int q = 0; q < ND; q++) qd[q] = 0;
@@ -677,46 +721,46 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int x = x0 + i;
-            const int xs = max(0, x - n);
-            int fsum[C], fcnt;
+            float fsum[C], fcnt;
             if constexpr (NH == 1 && NCT >= 0 && NCT <= 7) {
                 // FIR + IIR window sums stay below 2^16 for n <= 7 (14*14*255 + 49*255): add the packed
                 // pairs first, then split (the conversions take the 16-bit halves directly)
                 Ent T = aL;
                 eadd(T, aI);
                 if constexpr (C == 3) {
-                    fsum[0] = (int)(T.d[0] & 0xffffu); fsum[1] = (int)(T.d[0] >> 16);
-                    fsum[2] = (int)(T.d[1] & 0xffffu); fcnt = (int)(T.d[1] >> 16);     // the IIR entry has no count half
+                    fsum[0] = (float)(T.d[0] & 0xffffu); fsum[1] = (float)(T.d[0] >> 16);
+                    fsum[2] = (float)(T.d[1] & 0xffffu); fcnt = (float)(T.d[1] >> 16);     // the IIR entry has no count half
                 } else {
                     // gray: FIR {f | cnt<<16}, IIR {i} (a full dword, may exceed 16 bits only for n > 7)
-                    fsum[0] = (int)(T.d[0] & 0xffffu); fcnt = (int)(T.d[0] >> 16);
+                    fsum[0] = (float)(T.d[0] & 0xffffu); fcnt = (float)(T.d[0] >> 16);
                 }
             } else if constexpr (C == 3 && NH == 2) {
                 // three packed pairs per sum (left half, right half, IIR): the halves are added as they are
-                fsum[0] = (int)add_dw0(add_w0w0(aL.d[0], aR.d[0]), aI.d[0]);
-                fsum[1] = (int)add_dw1(add_w1w1(aL.d[0], aR.d[0]), aI.d[0]);
-                fsum[2] = (int)add_dw0(add_w0w0(aL.d[1], aR.d[1]), aI.d[1]);
-                fcnt = (int)add_w1w1(aL.d[1], aR.d[1]);
+                fsum[0] = (float)add_dw0(add_w0w0(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[1] = (float)add_dw1(add_w1w1(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[2] = (float)add_dw0(add_w0w0(aL.d[1], aR.d[1]), aI.d[1]);
+                fcnt = (float)add_w1w1(aL.d[1], aR.d[1]);
             } else if constexpr (C == 3) {
-                fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)(aI.d[0] & 0xffffu);
-                fsum[1] = (int)(aL.d[0] >> 16) + (int)(aI.d[0] >> 16);
-                fsum[2] = (int)(aL.d[1] & 0xffffu) + (int)(aI.d[1] & 0xffffu);
-                fcnt = (int)(aL.d[1] >> 16);
+                fsum[0] = (float)((aL.d[0] & 0xffffu) + (aI.d[0] & 0xffffu));
+                fsum[1] = (float)((aL.d[0] >> 16) + (aI.d[0] >> 16));
+                fsum[2] = (float)((aL.d[1] & 0xffffu) + (aI.d[1] & 0xffffu));
+                fcnt = (float)(aL.d[1] >> 16);
             } else {
-                fsum[0] = (int)(aL.d[0] & 0xffffu) + (int)aI.d[0];
-                fcnt = (int)(aL.d[0] >> 16);
-                if constexpr (NH == 2) { fsum[0] += (int)(aR.d[0] & 0xffffu); fcnt += (int)(aR.d[0] >> 16); }
+                unsigned f0 = (aL.d[0] & 0xffffu) + aI.d[0], c0 = aL.d[0] >> 16;
+                if constexpr (NH == 2) { f0 += aR.d[0] & 0xffffu; c0 += aR.d[0] >> 16; }
+                fsum[0] = (float)f0; fcnt = (float)c0;
             }
-            const int cnt = fcnt + (y - ys) * (x - xs);
-            const float rc = __builtin_amdgcn_rcpf((float)max(cnt, 1));   // 1 ulp: inside div_small's margin
-            const float hrc = 0.5f * rc;
+            // cnt = fcnt + (y - ys) * (x - xs), all small integers: exact in fp32
+            const float rc = __builtin_amdgcn_rcpf(__builtin_fmaxf(fcnt + kf[i], 1.0f));   // 1 ulp: inside the margin (div_small)
+            // floor(v / cnt) = round-to-nearest-even((v + 0.5) / cnt - 0.5): the argument is at least 0.5/cnt away from
+            // every half-integer, the arithmetic error stays below that (exhaustive device self-test), and
+            // v_cvt_pk_u8_f32 rounds to nearest even and drops the byte into place (tools/ubench/cvt_pk_u8.hip).
+            // cnt == 0 implies v == 0: rc = 1, offset 0, quotient 0 = the reference's `else: 0` (pyx:266-269)
+            const float qoff = __builtin_fmaf(rc, 0.5f, -0.5f);
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                // (v + 0.5) * rc as one fma; cnt == 0 implies v == 0 and the quotient 0.5 truncates to 0,
-                // which is the reference's `else: 0` (pyx:266-269) without a select
-                const unsigned q = (unsigned)__builtin_fmaf((float)fsum[c], rc, hrc);
                 const int jb = i * C + c;
-                qd[jb >> 2] |= q << (8 * (jb & 3));
+                qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rc, qoff), jb & 3, qd[jb >> 2]);
             }
             if (i + 1 < P) {      // slide to pixel x+1 (own columns' entries come from registers)
                 if constexpr (NH == 2) {
@@ -736,20 +780,25 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             if constexpr (C == 3) {
                 const unsigned e0 = __builtin_amdgcn_perm(0u, on, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on, 0x02020101u),
                                e2 = __builtin_amdgcn_perm(0u, on, 0x03030302u);
-                res[0] = ((r_cur.px[0] & e0) | (qd[0] & ~e0)) & pxm[0];
-                res[1] = ((r_cur.px[1] & e1) | (qd[1] & ~e1)) & pxm[1];
-                res[2] = ((r_cur.px[2] & e2) | (qd[2] & ~e2)) & pxm[2];
+                res[0] = ((RS.c.px[0] & e0) | (qd[0] & ~e0)) & pxm[0];
+                res[1] = ((RS.c.px[1] & e1) | (qd[1] & ~e1)) & pxm[1];
+                res[2] = ((RS.c.px[2] & e2) | (qd[2] & ~e2)) & pxm[2];
             } else {
-                res[0] = ((r_cur.px[0] & on) | (qd[0] & ~on)) & pxm[0];
+                res[0] = ((RS.c.px[0] & on) | (qd[0] & ~on)) & pxm[0];
             }
         }
 #pragma unroll
         for (int q = 0; q < ND; q++) prev[q] = res[q];
         if constexpr (!DB) lds_barrier();   // everyone is done reading the LDS rows (DB: the next row uses the other buffer)
 
-        r_enter = n_enter; r_leave = n_leave; r_cur = n_cur;
-#pragma unroll
-        for (int q = 0; q < ND; q++) o_leave[q] = n_oleave[q];
+        if constexpr (STRIP) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nmbp), "+v"(nmbl) : : "memory");
+            NS.mbp = nmbp; NS.mbl = nmbl;
+        }
+    };
+    for (int y = 0; y < h; y += 2) {
+        do_row(y, SA, SB);
+        if (y + 1 < h) do_row(y + 1, SB, SA);
     }
     if (h >= 1) store_row(h - 1, prev);
 }
@@ -1049,10 +1098,14 @@ __global__ __launch_bounds__(MAXT) void optimise_strip_kernel(const OptJob *jobs
 __global__ __launch_bounds__(256) void optimise_div_selftest_kernel(unsigned long long *bad) {
     const unsigned cnt = blockIdx.x + 1;                     // one workgroup per count
     const float rc = __builtin_amdgcn_rcpf((float)cnt), hrc = 0.5f * rc;
+    const float qoff = __builtin_fmaf(rc, 0.5f, -0.5f);
     unsigned long long nbad = 0;
     for (unsigned v = threadIdx.x; v <= 255u * cnt; v += 256) {
-        const unsigned q = (unsigned)__builtin_fmaf((float)v, rc, hrc);
+        const unsigned q = (unsigned)__builtin_fmaf((float)v, rc, hrc);                     // the wide kernel's form
         if (q != v / cnt) nbad++;
+        // the packed kernels' form: round-to-nearest-even byte conversion of (v + 0.5) / cnt - 0.5
+        const unsigned qb = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)v, rc, qoff), 1, 0u) >> 8;
+        if (qb != v / cnt) nbad++;
         if (div_small((int)v, rc) != v / cnt) nbad++;         // the unpacked kernel's form
     }
     if (nbad) atomicAdd(bad, nbad);
