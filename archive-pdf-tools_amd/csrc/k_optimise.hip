@@ -506,8 +506,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         }
     };
     // FIR entries of the 4 columns of a row: masked pixel bytes + selection bit
-    auto fir_entries = [&](const RowRegs<C, P> &r, Ent (&e)[P]) {
-        const unsigned on = on_bytes(r.m[0]);
+    auto fir_entries = [&](const RowRegs<C, P> &r, const unsigned on, Ent (&e)[P]) {
         const unsigned on01 = on & 0x01010101u;
         if constexpr (C == 3) {
             const unsigned d0 = r.px[0] & __builtin_amdgcn_perm(0u, on, 0x01000000u);   // [M0 M0 M0 M1]
@@ -546,9 +545,14 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
     for (int q = 0; q < ND; q++) prev[q] = 0;
 
+    // A layer whose mask is sparse (fg: the ink, a few percent of the page) mostly sees rows in which none of the wave's
+    // 256 columns is selected: such a row adds nothing to the FIR sums and is skipped for the whole wave
+    const bool sparse = !J.invert;
     auto fir_apply = [&](const RowRegs<C, P> &r, bool plus) {
+        const unsigned on = on_bytes(r.m[0]);
+        if (sparse && !__any(on != 0u)) return;
         Ent e[P];
-        fir_entries(r, e);
+        fir_entries(r, on, e);
 #pragma unroll
         for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
     };
@@ -1081,14 +1085,16 @@ __global__ __launch_bounds__(MAXT) void optimise_strip_kernel(const OptJob *jobs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int job = blockIdx.x / SI.S, strip = blockIdx.x - job * SI.S;
     const OptJob J = jobs[job];
+    // strips of up to 512 threads: the double-buffered LDS rows (one barrier per row) always fit; 1024 threads: single rows
+    constexpr bool DB = MAXT <= 512;
     if (J.mbits) {
-        if (J.n == 3) optimise_packed_rows<C, 1, 3, false, true, true>(J, smem, SI, job, strip);
-        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, false, true, true>(J, smem, SI, job, strip);
-        else optimise_packed_rows<C, NH, -1, false, true, true>(J, smem, SI, job, strip);
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, DB, true, true>(J, smem, SI, job, strip);
     } else {
-        if (J.n == 3) optimise_packed_rows<C, 1, 3, false, false, true>(J, smem, SI, job, strip);
-        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, false, false, true>(J, smem, SI, job, strip);
-        else optimise_packed_rows<C, NH, -1, false, false, true>(J, smem, SI, job, strip);
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, false, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, false, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, DB, false, true>(J, smem, SI, job, strip);
     }
 }
 
@@ -1177,7 +1183,7 @@ static int try_strips(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int 
     SI.S = S; SI.sw = sw; SI.mail = mail->buf.as<u32x4>() + 16;           // first 256 bytes: the error word
     SI.tagbase = mail->epoch << 16; SI.err = mail->buf.as<unsigned>();
     const int nent = T * 4 + 2 * n_max;
-    const size_t lds = (size_t)(nent + nent / 4 + 1) * ((c == 3) ? 16 : 8);
+    const size_t lds = (T <= 512 ? 2 : 1) * (size_t)(nent + nent / 4 + 1) * ((c == 3) ? 16 : 8);       // <= 512 threads: double-buffered rows
     const char *nm = c == 3 ? "optimise_rgb" : "optimise_gray";
 #define OPT_STRIP(CC, NHH, MT)                                                                                   \
     do {                                                                                                        \
@@ -1225,8 +1231,10 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, i
     const int wr = std::min(g.T * 4, (w + 3) & ~3);
     const int pnent = wr + 2 * n_max;
     const size_t plds1 = (size_t)(pnent + pnent / 4 + 1) * ((c == 3) ? 16 : 8);
-    // double buffering measured no faster than two barriers (9.45 vs 9.25 ms / 128 jobs): opt-in
-    static const bool want_db = getenv("MRCHIP_OPT_DB") != nullptr;
+    // double-buffered LDS rows (row y publishes into buffer y & 1: one barrier per row instead of two) whenever twice the
+    // rows fit: 256 page-layers of 4000 columns 6.06 -> 5.58 ms (round 1 measured no gain: the kernel then had more
+    // VALU work per row to hide the second barrier behind).  MRCHIP_OPT_DB=0 switches it off.
+    static const bool want_db = !(getenv("MRCHIP_OPT_DB") && atoi(getenv("MRCHIP_OPT_DB")) == 0);
     const bool db = want_db && 2 * plds1 <= 160 * 1024;
     const size_t plds = db ? 2 * plds1 : plds1;
 #define OPT_PACKED2(CC, NHH, MT, DBB, NAME)                                                             \
