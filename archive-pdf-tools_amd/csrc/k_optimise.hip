@@ -409,6 +409,9 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
     constexpr int ND = P * C / 4;                 // dwords of pixel bytes per thread-row
+    // n <= 7: FIR + IIR sums of a column (and of a whole window) fit the 16-bit lanes together, so the second LDS row
+    // carries FIR + IIR entries and ONE accumulator slides over the row: T(x+1) = T(x) + fir[x+n] + iir[x] - (fir+iir)[x-n]
+    constexpr bool SUMROW = (NH == 1 && NCT >= 0 && NCT <= 7);
     const uint8_t *__restrict__ mask = J.mask;
     const uint8_t *__restrict__ img = J.img;
     uint8_t *out = J.out;
@@ -684,12 +687,14 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const int e = eidx(x0 + i);
+            Ent second = iirE[i];
+            if constexpr (SUMROW) eadd(second, firE[i]);
             if constexpr (EW == 2) {
                 *reinterpret_cast<uint2 *>(firA + e) = make_uint2(firE[i].d[0], firE[i].d[1]);
-                *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(iirE[i].d[0], iirE[i].d[1]);
+                *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(second.d[0], second.d[1]);
             } else {
                 firA[e] = firE[i].d[0];
-                iirA[e] = iirE[i].d[0];
+                iirA[e] = second.d[0];
             }
         }
         lds_barrier();
@@ -706,7 +711,12 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         Ent aL, aR, aI;
 #pragma unroll
         for (int k = 0; k < EW; k++) { aL.d[k] = 0; aR.d[k] = 0; aI.d[k] = 0; }
-        if constexpr (NCT >= 0) {
+        if constexpr (SUMROW) {
+#pragma unroll
+            for (int j = -NCT; j < 0; j++) eadd(aL, lds_ld(iirA, x0 + j));          // (fir + iir)[x0 + j]
+#pragma unroll
+            for (int j = 0; j < NCT; j++) eadd(aL, j < P ? firE[j < P ? j : 0] : lds_ld(firA, x0 + j));
+        } else if constexpr (NCT >= 0) {
 #pragma unroll
             for (int j = -NCT; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
 #pragma unroll
@@ -729,8 +739,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             if constexpr (NH == 1 && NCT >= 0 && NCT <= 7) {
                 // FIR + IIR window sums stay below 2^16 for n <= 7 (14*14*255 + 49*255): add the packed
                 // pairs first, then split (the conversions take the 16-bit halves directly)
-                Ent T = aL;
-                eadd(T, aI);
+                const Ent T = aL;          // SUMROW: the one accumulator
                 if constexpr (C == 3) {
                     fsum[0] = (float)(T.d[0] & 0xffffu); fsum[1] = (float)(T.d[0] >> 16);
                     fsum[2] = (float)(T.d[1] & 0xffffu); fcnt = (float)(T.d[1] >> 16);     // the IIR entry has no count half
@@ -767,13 +776,19 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rc, qoff), jb & 3, qd[jb >> 2]);
             }
             if (i + 1 < P) {      // slide to pixel x+1 (own columns' entries come from registers)
-                if constexpr (NH == 2) {
-                    eadd(aL, firE[i]); esub(aL, lds_ld(firA, x - n));
-                    eadd(aR, lds_ld(firA, x + n)); esub(aR, firE[i]);
+                if constexpr (SUMROW) {
+                    eadd(aL, (i + NCT < P) ? firE[(i + NCT < P) ? i + NCT : 0] : lds_ld(firA, x + n));
+                    eadd(aL, iirE[i]);
+                    esub(aL, lds_ld(iirA, x - n));
                 } else {
-                    eadd(aL, lds_ld(firA, x + n)); esub(aL, lds_ld(firA, x - n));
+                    if constexpr (NH == 2) {
+                        eadd(aL, firE[i]); esub(aL, lds_ld(firA, x - n));
+                        eadd(aR, lds_ld(firA, x + n)); esub(aR, firE[i]);
+                    } else {
+                        eadd(aL, lds_ld(firA, x + n)); esub(aL, lds_ld(firA, x - n));
+                    }
+                    eadd(aI, iirE[i]); esub(aI, lds_ld(iirA, x - n));
                 }
-                eadd(aI, iirE[i]); esub(aI, lds_ld(iirA, x - n));
             }
         }
         }
