@@ -23,6 +23,11 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
+// the same for -n <= i < 2n (one reflection at most): what the fused kernel's tiles can ask for (n >= 2 * GF_RMAX,
+// offsets within GF_RMAX of the image) -- two compares and selects instead of the integer modulo, which the compiler
+// hoists in front of the interior / border branch and every lane then pays (it was a seventh of the kernel's VALU work)
+__device__ __forceinline__ int reflect_once(int i, int n) { return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i); }
+
 // vertical pass: one lane per 4 adjacent pixels (aligned dword loads, float4 store)
 __global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int spitch, size_t sstride, float *tmp,
                                                       int tpitch, size_t tstride, int w, int h, const GaussW *Gs) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
             } else {
 #pragma unroll
                 for (int i = 0; i < GF_SEG + 2 * R; i++) {
-                    const int yy = reflect_idx(min(y0 - R + i, h - 1 + R), h);   // rows past the tile's last row are unused
+                    const int yy = reflect_once(min(y0 - R + i, h - 1 + R), h);   // rows past the tile's last row are unused
                     in[i] = *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x);
                 }
             }
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
                     }
                 } else {
 #pragma unroll
-                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = (double)row[reflect_idx(x0 - RP + i, w)];
+                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = (double)row[reflect_once(x0 - RP + i, w)];
                 }
                 unsigned packed = 0;
 #pragma unroll
