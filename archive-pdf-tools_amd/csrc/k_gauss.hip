@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
 // scratch image never goes to HBM: 2 B/px of traffic instead of 10.
 // R is the largest radius in the batch; a page with a smaller radius has its table zero-padded to
 // R by the host: the extra outer taps add +0.0 first, which leaves every partial sum unchanged.
-constexpr int GF_TW = 256, GF_TH = 32, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 8, GF_THREADS = 320;
+constexpr int GF_TW = 256, GF_TH = 16, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 4, GF_THREADS = 320;
 
 template <int R>
 __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
@@ -154,22 +154,8 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
         const int x0 = X0 + 4 * q;
         if (x0 < w) {
             const bool interior = (x0 - R >= 0) && (x0 + 3 + R < w);
-#pragma unroll 2
-            for (int k = 0; k < GF_SEG; k++) {
-                const int ty = sgm * GF_SEG + k;
-                if (ty >= nrows) break;
-                const float *row = &tmpT[ty][0] - Xa;             // row[c] = intermediate of image column c
-                double v[4 + 2 * RP];                             // v[i] = column x0 - RP + i
-                if (interior) {
-#pragma unroll
-                    for (int i = 0; i < (4 + 2 * RP) / 4; i++) {
-                        const float4 f = *reinterpret_cast<const float4 *>(row + x0 - RP + 4 * i);
-                        v[4 * i] = (double)f.x; v[4 * i + 1] = (double)f.y; v[4 * i + 2] = (double)f.z; v[4 * i + 3] = (double)f.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = (double)row[reflect_once(x0 - RP + i, w)];
-                }
+            // the taps of one output row of this lane: v[i] = intermediate of column x0 - RP + i
+            auto finish_row = [&](int ty, const double (&v)[4 + 2 * RP]) {
                 unsigned packed = 0;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -182,6 +168,38 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
                 uint8_t *o = dst + (size_t)(Y0 + ty) * dpitch + x0;
                 if (x0 + 4 <= w) *reinterpret_cast<unsigned *>(o) = packed;
                 else for (int i = 0; x0 + i < w; i++) o[i] = (uint8_t)(packed >> (8 * i));
+            };
+            // Waves whose lanes all sit inside the image (every wave of a tile away from the left / right border) take
+            // 16-byte LDS reads; decided per WAVE: with a per-lane branch the compiler merges the two paths into
+            // per-element reads with selected indices.
+            if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+                // x0 - RP - Xa is a multiple of 4 (X0 - Xa is 0 or RP, x0 - X0 = 4q)
+                const int off = (x0 - RP - Xa) & ~3;
+#pragma unroll 2
+                for (int k = 0; k < GF_SEG; k++) {
+                    const int ty = sgm * GF_SEG + k;
+                    if (ty >= nrows) break;
+                    const float *seg = static_cast<const float *>(__builtin_assume_aligned(&tmpT[ty][off], 16));
+                    double v[4 + 2 * RP];
+#pragma unroll
+                    for (int i = 0; i < (4 + 2 * RP) / 4; i++) {
+                        const float4 f = *reinterpret_cast<const float4 *>(seg + 4 * i);
+                        v[4 * i] = (double)f.x; v[4 * i + 1] = (double)f.y; v[4 * i + 2] = (double)f.z; v[4 * i + 3] = (double)f.w;
+                    }
+                    finish_row(ty, v);
+                }
+            } else {
+                for (int k = 0; k < GF_SEG; k++) {
+                    const int ty = sgm * GF_SEG + k;
+                    if (ty >= nrows) break;
+                    const float *row = &tmpT[ty][0] - Xa;             // row[c] = intermediate of image column c
+                    double v[4 + 2 * RP];
+#pragma unroll
+                    for (int i = 0; i < 4 + 2 * RP; i++) v[i] = 0.0;
+#pragma unroll
+                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = (double)row[reflect_once(x0 - RP + i, w)];
+                    finish_row(ty, v);
+                }
             }
         }
     }
