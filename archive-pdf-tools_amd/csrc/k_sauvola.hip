@@ -29,7 +29,7 @@
 
 namespace mrchip {
 
-// Per window-row-count constants of the fast decision (one record per nrows = 1..wh, count = ww * nrows):
+// Per window-row-count constants of the table-driven decision (one record per nrows = 1..wh, count = ww * nrows):
 // exact truncating divisions by `count` as one 32x32->hi multiply + shift each (host-checked magic numbers).
 struct SauvolaRow {
     unsigned ms, mq;          // floor(S / count) = mulhi(S, ms) >> ss  for 0 <= S <= 255 count;  likewise Q <= 65025 count
@@ -46,9 +46,8 @@ struct SauvolaParams {
     int flags;
     int two;          // output columns per tile
     int th;           // output rows per tile
-    // fast decision (see sauvola_kernel): fp32 copies of the constants + the per-row table; fast == 0: fp64 only
+    // table-driven decision (see sauvola_kernel): per-row magic numbers; fast == 0: quotients in fp64 for every pixel
     int fast;
-    float km1f, k2f;
     const SauvolaRow *rows;   // [wh + 1], indexed by nrows
 };
 
@@ -117,25 +116,6 @@ __device__ __forceinline__ bool sauvola_form_dd(double Sd, double Qd, double pxd
     return kpos ? (neg || (lhs <= rhs)) : (neg && (lhs >= rhs));
 }
 
-// The reference's decision for one pixel from its window sums, out of line: the arbiter of the fast path's near-ties
-// (a pixel in ~10^5).  Kept out of the kernel body so that its fp64 temporaries do not count against the kernel's
-// register budget -- the kernel is latency-bound and lives on waves per SIMD.
-__device__ __attribute__((noinline)) bool sauvola_form_exact(unsigned S, unsigned Q, unsigned px, unsigned count, double km1,
-                                                             double k2, int kpos) {
-    const double rcd = rcp_nr((double)count), hrcd = 0.5 * rcd;
-    return sauvola_form_dd((double)S, (double)Q, (double)px, rcd, hrcd, kpos != 0, km1, k2);
-}
-
-// floor(n / c) for a per-lane divisor (window clipped by the left / right image border): fp32 estimate, within one
-// of the quotient for n / c <= 65025 (relative error 2^-22), then one exact remainder check each way.
-__device__ __forceinline__ unsigned div_lane(unsigned n, unsigned c, float rc) {
-    unsigned q = (unsigned)((float)n * rc);
-    const int rem = (int)(n - q * c);                 // true remainder in (-c, 2c): fits whatever the 32-bit wrap
-    q -= rem < 0 ? 1u : 0u;
-    q += rem >= (int)c ? 1u : 0u;
-    return q;
-}
-
 // ---- asynchronous row loads ----------------------------------------------------------------------------------
 // The three input rows of an output row (entering, leaving, centre) are loaded PF rows ahead into fixed register
 // slots.  hipcc cannot keep such loads in flight across the loop: with a variable number of stores between a load
@@ -175,7 +155,7 @@ __device__ __forceinline__ unsigned slot_dword(const typename Slot<KD>::T &r, in
 // caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
 // BOTH: every job also thresholds the image 255 - p (the hOCR-box launch; a page launch has BOTH = false and does
 // not carry the second polarity's registers).
-template <int K, bool MULTI, bool FAST, bool BOTH>
+template <int K, bool MULTI, bool FAST, bool BOTH, int PL = 32>
 __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
                                                      SauvolaParams P) {
     constexpr int KD = K / 4;
@@ -187,11 +167,29 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
     // accesses for one pixel index i are then consecutive dwords (conflict-free); the natural
     // [ci] order would put lanes 16 B apart = a 4-way bank conflict on every read.  PL lanes of
     // slack on both sides: halo lanes evaluate the formula on out-of-strip indices instead of
-    // branching around it (their results are never stored).
-    constexpr int PL = 32, LS = 64 + 2 * PL;
+    // branching around it (their results are never stored).  K * PL columns of slack must cover half a window:
+    // PL = 8 for the windows the pipeline uses (LDS per wave 5 KiB of prefix rows + 4 KiB of tables: 16 waves per CU
+    // fit), 32 for the widest ones.
+    constexpr int LS = 64 + 2 * PL;
     // (prefix of sums, prefix of sums of squares) side by side: one 8-byte LDS access per column end instead of two
     __shared__ uint2 EBuf[K * LS];
     auto pidx = [&](int ci) { const int c2 = ci + K * PL; return (c2 % K) * LS + c2 / K; };
+    // FAST: the two products of the reference's decision that depend on the (integer) mean only, for every mean
+    // 0..255, rounded exactly as the reference rounds them (pyx:147-150): mean * (k - 1) and (mean * mean) * k2.
+    // The decision then is: integer mean (index) -> two LDS reads -> add, two multiplies, two compares.
+    // (Measured: the tables save 3 VALU instructions per pixel but their per-lane LDS reads conflict on noisy images --
+    // 20 % of the LDS cycles -- and the kernel comes out 3 % slower on the c3gray batch, 7 % faster on blurred pages;
+    // computing the two products from the integer mean is the robust choice.  TABLES keeps the variant buildable.)
+    constexpr bool TABLES = false;
+    __shared__ double Tkm1[(FAST && TABLES) ? 256 : 1], Tk2[(FAST && TABLES) ? 256 : 1];
+    if constexpr (FAST && TABLES) {
+        for (int m = threadIdx.x; m < 256; m += 64) {
+            const double md = (double)m;
+            Tkm1[m] = __dmul_rn(md, P.km1);
+            Tk2[m] = __dmul_rn(__dmul_rn(md, md), P.k2);
+        }
+        lds_wave_sync();
+    }
 
     SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
     const int w = job.w, h = job.h;
@@ -385,9 +383,9 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
                 count = (unsigned)max(ncols * nrows, 1);
             }
         };
-        if constexpr (!FAST) {
-            // ---- general path: the reference's decision in fp64 in its own operation order (any k, R, window) ----
-            // one reciprocal per row where the whole strip sees the full window width (the count is uniform then)
+        // ---- general path: the reference's decision in fp64 in its own operation order (any k, R, window, count) ----
+        // one reciprocal per row where the whole strip sees the full window width (the count is uniform then)
+        auto general_row = [&]() {
             const double urcd = rcp_nr((double)ucount), uhrcd = 0.5 * urcd;
 #pragma unroll
             for (int i = 0; i < K; i++) {
@@ -410,71 +408,54 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
                     outb[i / 4] |= fb ? (1u << (8 * (i & 3))) : 0u;
                 }
             }
+        };
+        if constexpr (!FAST) {
+            general_row();
+        } else if (!(full_cols && RW.ok)) {
+            general_row();           // strips at the left / right image border, or a count without magic numbers
         } else {
-            // ---- fast decision (0 < k <= 1) -----------------------------------------------------------------------
-            // mean and floor(Q / count) exactly, as integers; the comparison in fp32 on the signed square t|t|
-            // (t <= 0 or t^2 <= rhs  <=>  t|t| <= rhs for rhs >= 0).  The fp32 value of t is within 2.3e-5 of the exact
-            // one and the right-hand side within 1.8e-7 relative, so |t|t| - rhs| > 4e-4 |t| + 1e-8 settles the
-            // comparison the reference makes in fp64 (derivation in DESIGN.md 3); a lane inside that band -- a pixel
-            // in ~10^5 -- is re-decided by sauvola_form_exact.  A window of mean 0 has rhs = 0 and t = p exactly:
-            // nothing to arbitrate (all-black regions would otherwise send every pixel there).
-            const float C1 = 4e-4f, C3 = 1e-8f;
-            unsigned unc_a = 0, unc_b = 0;            // wave-uniform: columns i where some lane sits on a near-tie
-            auto fast_px = [&](float mean, float qf, float pxf, unsigned &out, unsigned &unc_cols, int i) {
-                const float mm = mean * mean;
-                const float var = qf - mm;
-                const float t = __builtin_fmaf(mean, P.km1f, pxf);
-                const float d = t * __builtin_fabsf(t) - (mm * P.k2f) * var;
-                const bool unc = (__builtin_fabsf(d) <= __builtin_fmaf(__builtin_fabsf(t), C1, C3)) & (mean != 0.0f);
-                unc_cols |= __builtin_amdgcn_ballot_w64(unc) ? (1u << i) : 0u;
-                out |= (d <= 0.0f) ? (1u << (8 * (i & 3))) : 0u;                      // form
-            };
-            auto fast_row = [&](auto both, auto uniform) {
-#pragma unroll
-                for (int i = 0; i < K; i++) {
-                    unsigned S, Q, count;
-                    window(i, S, Q, count);
-                    const float pxf = (float)((cv[i / 4] >> (8 * (i & 3))) & 0xffu);
-                    if constexpr (decltype(uniform)::value) {
-                        // one count for the whole row: magic-number divisions (SauvolaRow)
-                        fast_px((float)(__umulhi(S, RW.ms) >> RW.ss), (float)(__umulhi(Q, RW.mq) >> RW.sq), pxf,
-                                outa[i / 4], unc_a, i);
-                        if constexpr (decltype(both)::value) {    // the window on 255 - p: sums from S, Q and the count
-                            const unsigned Si = RW.c255 - S, Qi = (Q + RW.c65025) - 510u * S;
-                            fast_px((float)(__umulhi(Si, RW.ms) >> RW.ss), (float)(__umulhi(Qi, RW.mq) >> RW.sq),
-                                    255.0f - pxf, outb[i / 4], unc_b, i);
-                        }
-                    } else {
-                        // strips at the left / right image border (or a row count without magic numbers)
-                        const float rc = __builtin_amdgcn_rcpf((float)count);
-                        fast_px((float)div_lane(S, count, rc), (float)div_lane(Q, count, rc), pxf, outa[i / 4], unc_a, i);
-                        if constexpr (decltype(both)::value) {
-                            const unsigned Si = 255u * count - S, Qi = (Q + 65025u * count) - 510u * S;
-                            fast_px((float)div_lane(Si, count, rc), (float)div_lane(Qi, count, rc), 255.0f - pxf,
-                                    outb[i / 4], unc_b, i);
-                        }
-                    }
+            // ---- table path: one count for the whole row ------------------------------------------------------------
+            // mean = S / count and Q / count as exact integer quotients (magic-number multiplies, host-checked for
+            // every dividend the window can produce); variance = Q/count - mean^2 as an integer (>= 0 by Cauchy-Schwarz
+            // and floor monotonicity) converted once -- the very value the reference's fp64 subtraction of two integers
+            // yields; mean * (k-1) and mean^2 * k2 from the tables.  What remains of pyx:147-151 is its own sequence:
+            // tmp = px + mean*(k-1); lhs = tmp*tmp; rhs = (mean^2*k2) * variance; two compares.  Bit-exact by
+            // construction: every fp64 operation is the reference's, on the reference's operands.
+            // (k >= 0 here: the launcher sends negative k to the general kernel.)  The form bits of a lane's K pixels are
+            // shifted into one register through the carry: v_addc(bits, bits, form) = 2 bits + form, one instruction per
+            // pixel where select + or take two; pixels run K-1 .. 0 so that bit i is pixel i.
+            auto form_tab = [&](unsigned S, unsigned Q, double pxd, unsigned &bits) {
+                const unsigned mean = __builtin_amdgcn_ubfe(__umulhi(S, RW.ms), (unsigned)RW.ss, 8u);   // <= 255: a table index even in halo lanes
+                const unsigned q = __umulhi(Q, RW.mq) >> RW.sq;
+                const double vard = (double)(q - __umul24(mean, mean));
+                double tkm1, tk2;
+                if constexpr (TABLES) { tkm1 = Tkm1[mean]; tk2 = Tk2[mean]; }
+                else {
+                    const double meand = (double)mean;
+                    tkm1 = __dmul_rn(meand, P.km1);
+                    tk2 = __dmul_rn(__dmul_rn(meand, meand), P.k2);
                 }
+                const double tmp = __dadd_rn(pxd, tkm1);
+                const double lhs = __dmul_rn(tmp, tmp);
+                const double rhs = __dmul_rn(tk2, vard);
+                // two ballots of plain compares OR-ed on the scalar side (the ballot of `a || b` goes through a VGPR bool)
+                const unsigned long long form = __builtin_amdgcn_ballot_w64(tmp <= 0) | __builtin_amdgcn_ballot_w64(lhs <= rhs);
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(form) : "vcc");
             };
-            const bool uni = full_cols && RW.ok;
-            if (uni) fast_row(std::integral_constant<bool, BOTH>{}, std::true_type{});
-            else fast_row(std::integral_constant<bool, BOTH>{}, std::false_type{});
-            if (unc_a | unc_b) {                  // rare
+            unsigned bits_a = 0, bits_b = 0;
 #pragma unroll
-                for (int i = 0; i < K; i++) {
-                    if (!(((unc_a | unc_b) >> i) & 1u)) continue;
-                    unsigned S, Q, count;
-                    window(i, S, Q, count);
-                    const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
-                    const unsigned bit = 1u << (8 * (i & 3));
-                    const bool fa = sauvola_form_exact(S, Q, px, count, P.km1, P.k2, 1);
-                    outa[i / 4] = (outa[i / 4] & ~bit) | (fa ? bit : 0u);
-                    if constexpr (BOTH) {
-                        const bool fb = sauvola_form_exact(255u * count - S, (Q + 65025u * count) - 510u * S, 255u - px, count,
-                                                           P.km1, P.k2, 1);
-                        outb[i / 4] = (outb[i / 4] & ~bit) | (fb ? bit : 0u);
-                    }
-                }
+            for (int i = K - 1; i >= 0; i--) {
+                unsigned S, Q, count;
+                window(i, S, Q, count);
+                const double pxd = (double)((cv[i / 4] >> (8 * (i & 3))) & 0xffu);
+                form_tab(S, Q, pxd, bits_a);
+                if constexpr (BOTH)       // the window on 255 - p: sums from S, Q and the count (integers below 2^32)
+                    form_tab(RW.c255 - S, (Q + RW.c65025) - 510u * S, 255.0 - pxd, bits_b);
+            }
+#pragma unroll
+            for (int q = 0; q < KD; q++) {          // bit i -> byte i (0/1)
+                outa[q] = __umul24((bits_a >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
+                if constexpr (BOTH) outb[q] = __umul24((bits_b >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
             }
         }
         // form -> stored value (pyx:153 `0 if formres else 1`, complemented for mrc.py:85's np.invert), columns
@@ -618,10 +599,22 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     const bool both = h_jobs[0].dst_inv != nullptr;
     for (int i = 1; i < njobs; i++)
         if ((h_jobs[i].dst_inv != nullptr) != both) { set_error("sauvola: jobs with and without a second polarity in one launch"); return MRCHIP_E_ARG; }
+    // slack lanes of the LDS prefix rows: 8 when K * 8 columns cover half the window (the pipeline's windows), else 32
+    const bool small_pl = K <= 8 && P.l + K <= K * 8;
 #define SAUVOLA_LAUNCH(MULTI_, FAST_, BOTH_)                                                                     \
-    LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_>), grid, dim3(64), 0, s, \
-                                                     h_jobs[0], d_jobs, P))
-    const int sel = (single ? 0 : 4) | (P.fast ? 2 : 0) | (both ? 1 : 0);
+    do {                                                                                                         \
+        if (small_pl && K <= 8)                                                                                  \
+            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_, (K <= 8 ? 8 : 32)>), grid, \
+                                                             dim3(64), 0, s, h_jobs[0], d_jobs, P));              \
+        else                                                                                                     \
+            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_, 32>), grid, dim3(64), 0, s, \
+                                                             h_jobs[0], d_jobs, P));                              \
+    } while (0)
+    // the integer-quotient decision pays on the page kernel (one polarity: 38 -> 30 VALU instructions per pixel, 128 blurred
+    // pages 2.48 -> 2.33 ms, the noisy c3gray batch unchanged); the two-polarity box kernel measured 4 % slower with it
+    // (same-box A/B), so the boxes keep the fp64 quotients unless MRCHIP_SAUVOLA_FAST=2 asks otherwise
+    const bool fast = P.fast && (!both || P.fast >= 2);
+    const int sel = (single ? 0 : 4) | (fast ? 2 : 0) | (both ? 1 : 0);
     switch (sel) {
         case 0: SAUVOLA_LAUNCH(false, false, false); break;
         case 1: SAUVOLA_LAUNCH(false, false, true); break;
@@ -685,18 +678,18 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
     P.l = (ww + 1) / 2; P.r = ww / 2; P.o = (wh + 1) / 2; P.u = wh / 2;
     P.k = k; P.km1 = k - 1; P.k2 = k * k / R / R;     // pyx:62
     P.flags = flags;
-    // fast decision: 0 < k <= 1 (|k - 1| <= 1 bounds the fp32 error of t), a right-hand-side factor that is a
-    // normal fp32 number, a window of at least two pixels whose sum of squares fits 32 bits
-    // The fp32 / integer "fast" decision is kept as a measured experiment: on gfx950 an fp64 fma, mul,
-    // add or conversion issues at the same ~4.3 cycles per wave as an fp32 or integer one (profiles/r02_valu_rates.txt),
-    // so the guarded path executes as many instructions per pixel as the exact one (SQ_INSTS_VALU 55.8 vs 53.2 per
-    // pixel-wave) and is not faster.  MRCHIP_SAUVOLA_FAST=1 selects it; the parity tests run it both ways.
+    // Table-driven decision (sauvola_kernel, FAST): exact integer quotients by the row's uniform count + LDS tables of
+    // the mean-dependent fp64 products; every fp64 operation left is the reference's own, so the result is bit-exact by
+    // construction for any k and R.  Rows whose count has no 32-bit magic numbers, and strips at the left / right image
+    // border (per-lane counts), take the general fp64 path inside the same kernel.  MRCHIP_SAUVOLA_FAST=0 forces the
+    // general path everywhere (the parity tests run both).
+    // (Round 2 first tried a guarded fp32 comparison here: bit-exact with its fp64 arbiter, but no fewer instructions
+    // than the fp64 path -- DESIGN.md 5; it is gone, git history has it.)
     const char *fast_env = getenv("MRCHIP_SAUVOLA_FAST");
-    const int no_fast = !(fast_env && atoi(fast_env) != 0);
-    P.km1f = (float)P.km1; P.k2f = (float)P.k2;
+    const int no_fast = fast_env && atoi(fast_env) == 0;
     P.rows = row_table(ctx, ww, wh);
     if (!P.rows) { set_error("sauvola: cannot allocate the row table"); return MRCHIP_E_NOMEM; }
-    P.fast = !no_fast && k > 0 && k <= 1 && P.k2 > 1e-30 && P.k2 < 1e30 && (long long)ww * wh >= 2;
+    P.fast = (!no_fast && k >= 0) ? ((fast_env && atoi(fast_env) >= 2) ? 2 : 1) : 0;
     int maxw = 0, maxh = 0;
     double alg = 0;
     for (int i = 0; i < njobs; i++) {

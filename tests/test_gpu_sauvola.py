@@ -111,3 +111,28 @@ def test_fp64_quotients_equal_integer_division_for_every_divisor():
     bad = C.c_longlong(-1)
     _lib.check(_lib.load().mrchip_selftest_sauvola_quotients(_lib.default_context().handle, C.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.parametrize('mode', ['0', '1', '2'])
+def test_quotient_paths_agree_with_the_oracle(mode, monkeypatch):
+    """The decision has two forms of its truncating quotients: fp64 (floor of an fma with a refined reciprocal, any
+    count) and integer magic-number multiplies by the row's uniform count (default for one polarity; MRCHIP_SAUVOLA_FAST=2
+    also for the two-polarity hOCR-box launch, =0 nowhere).  Everything after the quotients is the reference's own fp64
+    sequence either way: all three settings must equal the oracle on pages (borders = per-lane counts, top / bottom =
+    changing row counts) and on the box masks."""
+    from mrchip import mrc
+    monkeypatch.setenv('MRCHIP_SAUVOLA_FAST', mode)
+    rng = np.random.RandomState(5 + int(mode))
+    for (h, w, ww, wh, k) in [(260, 1300, 51, 51, 0.34), (90, 520, 51, 51, 0.1), (300, 700, 31, 75, 0.34), (64, 2000, 91, 91, 0.5),
+                              (40, 300, 51, 51, 0.0)]:
+        for img in (rng.randint(0, 256, (h, w)).astype(np.uint8), np.clip(rng.normal(120, 2.5, (h, w)), 0, 255).astype(np.uint8),
+                    synth.synth_page(w, h, 1, seed=h + w + 1, noise_sigma=4.0, line_div=max(2, h // 30))[0]):
+            got, exp = run_gpu(img, ww, wh, k), run_cpu(img, ww, wh, k)
+            assert np.array_equal(got, exp), (mode, h, w, ww, wh, k, int((got != exp).sum()))
+    # the two-polarity launch: create_hocr_mask against the oracle
+    img, hocr = synth.synth_page(900, 700, 1, seed=77, noise_sigma=5.0, line_div=14)
+    m_gpu = np.zeros(img.shape, dtype=np.bool_)
+    m_cpu = np.zeros(img.shape, dtype=np.bool_)
+    mrc.create_hocr_mask(img, m_gpu, hocr)
+    O.create_hocr_mask(img, m_cpu, mrc.hocr_boxes(hocr, 900, 700), None)
+    assert np.array_equal(m_gpu, m_cpu), (mode, int((m_gpu != m_cpu).sum()))
