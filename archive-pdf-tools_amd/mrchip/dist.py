@@ -6,6 +6,8 @@ Two transports with one interface (bcast_obj / allgather_obj / max_f64 / barrier
   RcclComm   the native one: libmrchip's mrchip_comm_* calls, i.e. RCCL over xGMI through ctypes, no PyTorch.
              The 128-byte RCCL unique id goes from rank 0 to the others through a file (one node).
   TorchComm  torch.distributed with a CPU backend (gloo): the world_size-2 CPU tests of the sharding logic.
+  FileComm   files of the node's temporary directory: the fallback make_comm() takes when RCCL cannot make a
+             communicator on every rank, so that a multi-GPU run still reports instead of hanging.
 """
 import ctypes as C
 import json
@@ -144,6 +146,100 @@ class RcclComm(_Comm):
                     os.remove(self._path)
                 except OSError:
                     pass
+
+
+class FileComm(_Comm):
+    """Control data through files of one node's temporary directory: the fallback when RCCL cannot make a
+    communicator (no usable network interface for its bootstrap, a rank without librccl ...), and the transport over
+    which the ranks agree whether RCCL came up everywhere.  Exchange number k of rank r is the file `<base>.<k>.<r>`
+    (written under a temporary name and renamed: readers see all of it or nothing).  A rank removes a file of its own
+    once it has COMPLETED a later exchange in which every rank writes: a rank writes there only after it is through
+    with everything before, so by then every rank has read the file."""
+
+    def __init__(self, rank, world, base=None, timeout=600.0):
+        self.rank, self.world = rank, world
+        self.base = base or (rendezvous_path() + '_fc')
+        self.timeout = timeout
+        self.k = 0
+        self.mine = []              # exchange numbers of this rank's files still on disk
+        self.full_done = -1         # last completed exchange in which every rank wrote
+
+    def _name(self, k, r):
+        return '%s.%d.%d' % (self.base, k, r)
+
+    def _exchange(self, raw, writers):
+        k = self.k
+        self.k += 1
+        for old in [x for x in self.mine if x < self.full_done]:
+            try:
+                os.remove(self._name(old, self.rank))
+            except OSError:
+                pass
+            self.mine.remove(old)
+        if self.rank in writers:
+            path = self._name(k, self.rank)
+            with open(path + '.tmp', 'wb') as f:
+                f.write(raw)
+            os.replace(path + '.tmp', path)
+            self.mine.append(k)
+        out = {}
+        t0 = time.time()
+        for r in writers:
+            path = self._name(k, r)
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout:
+                    raise RuntimeError('FileComm: %s did not appear within %.0f s' % (path, self.timeout))
+                time.sleep(0.002)
+            with open(path, 'rb') as f:
+                out[r] = f.read()
+        if len(writers) == self.world:
+            self.full_done = k
+        return out
+
+    def bcast_bytes(self, raw, root=0):
+        return self._exchange(raw, [root])[root]
+
+    def allgather_bytes(self, raw):
+        got = self._exchange(raw, list(range(self.world)))
+        return [got[r] for r in range(self.world)]
+
+    def max_f64(self, value):
+        parts = self.allgather_bytes(np.array([float(value)], dtype=np.float64).tobytes())
+        return float(max(np.frombuffer(p, dtype=np.float64)[0] for p in parts))
+
+    def close(self):
+        self.barrier()
+        self.barrier()              # completes an all-writers exchange after the first one: everything before it may go
+        self._exchange(b'', [])     # (removes them; the 8-byte files of the last barrier stay behind)
+
+
+def make_comm(ctx, rank, world, timeout=90.0):
+    """The control-plane transport of a multi-rank run: RCCL if every rank gets its communicator, else files.
+    ncclCommInitRank blocks until all ranks have joined and cannot be cancelled, so it runs on a helper thread with a
+    deadline; the ranks then tell each other (through files) whether it returned, and only if it did everywhere is the
+    RCCL communicator used.  Returns (comm, description)."""
+    if world == 1:
+        return SoloComm(), 'none (one rank)'
+    fc = FileComm(rank, world)
+    import threading
+    box = {}
+
+    def init():
+        try:
+            box['comm'] = RcclComm(ctx, rank, world)
+        except Exception as e:          # noqa: BLE001 - any failure means "no RCCL on this rank"
+            box['err'] = '%s: %s' % (type(e).__name__, e)
+
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(timeout)
+    ok = 'comm' in box
+    flags = fc.allgather_obj({'ok': ok, 'err': box.get('err', 'ncclCommInitRank did not return within %.0f s' % timeout if not ok else '')})
+    if all(f['ok'] for f in flags):
+        fc.close()
+        return box['comm'], 'rccl'
+    why = '; '.join('rank %d: %s' % (i, f['err']) for i, f in enumerate(flags) if not f['ok'])
+    return fc, 'files (RCCL unavailable -- %s)' % why
 
 
 class TorchComm(_Comm):

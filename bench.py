@@ -210,6 +210,7 @@ def main():
     lib = _lib.load()
     ctx = _lib.Context(local_rank % max(1, _lib.mrchip_visible_devices()))
     info = ctx.info()
+    transport = 'none (one rank)'
     if world == 1:
         comm = mdist.SoloComm()
     elif os.environ.get('MRCHIP_BENCH_COMM') == 'gloo':
@@ -218,8 +219,9 @@ def main():
         import torch.distributed as tdist
         tdist.init_process_group('gloo')
         comm = mdist.TorchComm(tdist)
+        transport = 'gloo (test hook)'
     else:
-        comm = mdist.RcclComm(ctx, rank, world)
+        comm, transport = mdist.make_comm(ctx, rank, world)      # RCCL; files of /tmp only if RCCL cannot come up on every rank
 
     # ---- work queue: rank 0 owns the descriptor table and broadcasts it over RCCL (bytes, not pixels); page j of the
     # global list (world * pages-per-GPU pages) belongs to rank j mod world and is the synthetic page of seed
@@ -416,7 +418,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'config': {'workload': cfg['label'], 'pages_per_gpu_per_step': cfg['pages'], 'batches_in_flight': nb,
                        'distinct_pages_per_gpu': nd, 'hocr_boxes_per_page': int(len(host_pages[0][2])),
-                       'sharding': 'page i of the global list -> rank i mod N (RCCL carries descriptors, records and the time only)'},
+                       'sharding': 'page i of the global list -> rank i mod N (the control plane carries descriptors, records '
+                                   'and the time only)', 'control_plane': transport},
             'roofline': roof, 'cpu_baseline': cpu,
             'pipeline_alg_GBps': round(alg_per_step / step_s / 1e9, 1),      # all kernels' algorithmic bytes / step time
             'pages_per_s': round(total_pages / dt, 2),

@@ -76,3 +76,58 @@ def test_solo_comm_and_rendezvous_name():
     c.barrier()
     p = mdist.rendezvous_path()
     assert os.path.basename(p).startswith('mrchip_rccl_id_')
+
+
+FILE_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, os.path.join(%r, 'archive-pdf-tools_amd'))
+    from mrchip import dist as mdist
+    rank, world, base, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    if mode == 'file':
+        comm, how = mdist.FileComm(rank, world, base=base, timeout=60), 'files'
+    else:
+        # no GPU here: RCCL cannot make a communicator, every rank has to come out on the file transport
+        os.environ['MRCHIP_RENDEZVOUS'] = base
+        class Ctx: handle = None
+        comm, how = mdist.make_comm(Ctx(), rank, world, timeout=20)
+    desc = comm.bcast_obj({'pages': 11, 'note': 'x' * 300} if rank == 0 else None)
+    mine = mdist.shard_pages(desc['pages'], rank, world)
+    for rep in range(5):                                   # several rounds: files of old exchanges are removed on the way
+        elapsed = comm.max_f64(1.0 + rank + rep)
+    parts = comm.allgather_obj([{'page': p, 'rank': rank, 'pad': 'y' * (rank * 5)} for p in mine])
+    other = comm.bcast_obj({'from': world - 1} if rank == world - 1 else None, root=world - 1)
+    comm.barrier()
+    comm.close()
+    if rank == 0:
+        print(json.dumps({'how': how, 'desc_pages': desc['pages'], 'elapsed': elapsed, 'other': other,
+                          'records': [r for part in parts for r in part]}))
+''')
+
+
+def _run_file_ranks(tmp_path, world, mode):
+    import json
+    script = tmp_path / 'fworker.py'
+    script.write_text(FILE_WORKER % ROOT)
+    base = str(tmp_path / 'fc')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), base, mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    out = json.loads([l for l in outs[0][0].splitlines() if l.startswith('{')][-1])
+    assert out['desc_pages'] == 11 and out['other'] == {'from': world - 1}
+    assert out['elapsed'] == 1.0 + (world - 1) + 4
+    assert sorted(r['page'] for r in out['records']) == list(range(11))
+    assert all(r['rank'] == r['page'] % world for r in out['records'])
+    left = [f for f in os.listdir(tmp_path) if f.startswith('fc')]
+    assert len(left) <= 2 * world, left                      # only the last barrier's files may remain
+    return out
+
+
+def test_file_comm_three_ranks(tmp_path):
+    assert _run_file_ranks(tmp_path, 3, 'file')['how'] == 'files'
+
+
+def test_make_comm_falls_back_to_files_when_rccl_cannot_start(tmp_path):
+    how = _run_file_ranks(tmp_path, 2, 'auto')['how']
+    assert how.startswith('files (RCCL unavailable'), how
