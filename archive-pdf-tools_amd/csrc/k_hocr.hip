@@ -13,17 +13,32 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
     uint8_t *mask = B.mask;
     const int mpitch = B.mpitch, nb = B.page_end;
     const int bh = B.b - B.t;
-    // one lane per 16 pixels (four dwords), dword-aligned in the MASK's coordinates (the box scratch has the
-    // same column phase mod 16, so its dwords line up too)
-    const int xa0 = (B.l & ~3) + (blockIdx.x * 256 + threadIdx.x) * 16;   // absolute column of the first dword
+    // one lane per 16 pixels, 16-byte aligned in the MASK's coordinates (the box scratch has the same column phase
+    // mod 16, so its 16-byte groups line up too): lanes wholly inside the box move one uint4 each way
+    const int xa0 = (B.l & ~15) + (blockIdx.x * 256 + threadIdx.x) * 16;   // absolute column of the lane's first pixel
     if (xa0 >= B.r) return;
     const uint8_t *th = B.decision == 1 ? B.th : B.thi;
+    const bool whole = xa0 >= B.l && xa0 + 16 <= B.r;
     for (int y = blockIdx.y; y < bh; y += gridDim.y) {
         const int py = B.t + y;
+        const uint8_t *tp = th + (ptrdiff_t)y * B.pitch + (xa0 - B.l);
+        uint8_t *mp = mask + (size_t)py * mpitch + xa0;
+        if (whole && !B.overlapped) {
+            // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel has
+            // exactly one owner (box, lane), so the read-modify-write is race-free
+            uint4 v = *reinterpret_cast<const uint4 *>(tp);
+            if (or_mode) {
+                const uint4 m = *reinterpret_cast<const uint4 *>(mp);
+                v.x |= m.x; v.y |= m.y; v.z |= m.z; v.w |= m.w;
+            }
+            *reinterpret_cast<uint4 *>(mp) = v;
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int xa = xa0 + 4 * q;
             if (xa >= B.r) break;
+            if (xa + 4 <= B.l) continue;
             unsigned keep = 0;                       // byte mask of pixels this box owns
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -42,19 +57,18 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
                 }
             }
             if (!keep) continue;
-            const unsigned v = *reinterpret_cast<const unsigned *>(th + (ptrdiff_t)y * B.pitch + (xa - B.l));
-            uint8_t *mp = mask + (size_t)py * mpitch + xa;
-            // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel
-            // has exactly one owner (box, lane), so the read-modify-write is race-free
+            uint8_t *mq8 = mp + 4 * q;
             if (keep == 0xffffffffu) {
-                unsigned *mq = reinterpret_cast<unsigned *>(mp);
+                const unsigned v = *reinterpret_cast<const unsigned *>(tp + 4 * q);
+                unsigned *mq = reinterpret_cast<unsigned *>(mq8);
                 *mq = or_mode ? (*mq | v) : v;
-            } else {      // partial dword: byte accesses, so that a neighbouring box's bytes are never rewritten
+            } else {      // partial dword: byte accesses, so that a neighbouring box's bytes are never touched (and the
+                          // scratch is never read in front of the box's first column)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if ((keep >> (8 * i)) & 0xffu) {
-                        const uint8_t bv = (uint8_t)(v >> (8 * i));
-                        mp[i] = or_mode ? (uint8_t)(mp[i] | bv) : bv;
+                        const uint8_t bv = tp[4 * q + i];
+                        mq8[i] = or_mode ? (uint8_t)(mq8[i] | bv) : bv;
                     }
             }
         }
@@ -67,7 +81,7 @@ int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, i
     // grid.z is limited to 65535: big batches of small pages can hold more boxes than that
     for (int first = 0; first < nb; first += MAX_GRID_Z) {
         const int cnt = std::min(MAX_GRID_Z, nb - first);
-        dim3 grid(cdiv(cdiv(maxw + 3, 16), 256), std::min(maxh, 64), cnt);
+        dim3 grid(cdiv(cdiv(maxw + 15, 16) + 1, 256), std::min(maxh, 64), cnt);
         LAUNCH(ctx, s, "hocr_commit", (or_mode ? 3.0 : 2.0) * area * cnt / nb,
                hipLaunchKernelGGL(hocr_commit_kernel, grid, dim3(256), 0, s, d_boxes, first, or_mode));
     }
