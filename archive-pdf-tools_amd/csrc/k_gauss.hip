@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
 // scratch image never goes to HBM: 2 B/px of traffic instead of 10.
 // R is the largest radius in the batch; a page with a smaller radius has its table zero-padded to
 // R by the host: the extra outer taps add +0.0 first, which leaves every partial sum unchanged.
-constexpr int GF_TW = 256, GF_TH = 16, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 4, GF_THREADS = 320;
+// 240 columns: the tile plus its halo is at most 64 dword groups (4 * 64 >= 240 + 2 * 8), so the vertical pass fills
+// exactly the four waves the horizontal pass uses (256 + halo needed a fifth wave with 20 live lanes)
+constexpr int GF_TW = 240, GF_TH = 16, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 4, GF_THREADS = 256, GF_GROUPS = 64;
 
 template <int R>
 __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
@@ -100,14 +102,14 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
     const int X0 = blockIdx.x * GF_TW, Y0 = blockIdx.y * GF_TH;
     const int Xa = max(0, X0 - R) & ~3;                       // first tile column, dword aligned
     const int Xe = min(w, X0 + GF_TW + R);                    // one past the last needed column
-    const int ngroups = (Xe - Xa + 3) >> 2;                   // <= 69
+    const int ngroups = (Xe - Xa + 3) >> 2;                   // <= 64
     const int nrows = min(GF_TH, h - Y0);
     double wt[R + 1];                                          // wt[k] = weight of offset -(R-k) (and +(R-k))
 #pragma unroll
     for (int k = 0; k <= R; k++) wt[k] = G.w[k];
     // ---- vertical pass: global -> float32 LDS tile ----
     {
-        const int g = tid % 69, sgm = tid / 69;               // 69 column groups x 4 row segments (276 lanes)
+        const int g = tid % GF_GROUPS, sgm = tid / GF_GROUPS;  // 64 column groups x 4 row segments
         if (g < ngroups && sgm < GF_TH / GF_SEG) {
             const int x = Xa + 4 * g, y0 = Y0 + sgm * GF_SEG;
             unsigned in[GF_SEG + 2 * R];
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
     __syncthreads();
     // ---- horizontal pass: LDS -> global.  lane = (4 adjacent columns, 8 consecutive rows): the 4 + 2R floats a lane
     // needs come in as 16-byte LDS reads and are widened to double once each; the four result bytes leave as one dword
-    if (tid < GF_TW) {
+    {
         constexpr int RP = (R <= 4) ? 4 : 8;                      // halo rounded up to whole float4s
         const int q = tid & 63, sgm = tid >> 6;
         const int x0 = X0 + 4 * q;
-        if (x0 < w) {
+        if (q < GF_TW / 4 && x0 < w) {
             const bool interior = (x0 - R >= 0) && (x0 + 3 + R < w);
             // the taps of one output row of this lane: v[i] = intermediate of column x0 - RP + i
             auto finish_row = [&](int ty, const double (&v)[4 + 2 * RP]) {
