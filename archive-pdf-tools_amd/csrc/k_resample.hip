@@ -420,9 +420,9 @@ __global__ __launch_bounds__(64 * WPB) void resize_mm_kernel(const uint8_t *src,
 // panel (one barrier per line group) and every wave takes its operands from there.  2.4x fewer
 // load instructions, no overlap re-fetched.  Needs 16-byte aligned tile bases (build_mm) and a
 // span of at most 1024 bytes.
-constexpr int PNW = 16;         // waves = tiles per workgroup
-template <int KB>
-__global__ __launch_bounds__(64 * PNW) void resize_mm_panel_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
+constexpr int PNW = 16;         // waves = tiles per workgroup (widest form; 8 where the narrower panel fits its 512 loader lanes)
+template <int KB, int NW>
+__global__ __launch_bounds__(64 * NW) void resize_mm_panel_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
                                                                    uint8_t *dst, int dpitch, size_t dstride, int nout, int ntiles,
                                                                    const int32_t *kbase, const int32_t *bias, const v4i *btab,
                                                                    int quads_per_wave, int pad_ok, int gx, int gy, int gz,
@@ -434,9 +434,9 @@ __global__ __launch_bounds__(64 * PNW) void resize_mm_panel_kernel(const uint8_t
     constexpr int OSTR = 80;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *inP = smem;                                        // [2][16][pws]
-    unsigned char *outP = smem + 2 * 16 * pws;                        // [PNW][16][OSTR]
+    unsigned char *outP = smem + 2 * 16 * pws;                        // [NW][16][OSTR]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile0 = bx * PNW, tile = tile0 + wv;
+    const int tile0 = bx * NW, tile = tile0 + wv;
     const bool active = tile < ntiles;
     src += (size_t)bz * sstride;
     dst += (size_t)bz * dstride;
@@ -560,11 +560,17 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
     t.KB = KB;
     // span of the 16 tiles of a workgroup (panel kernel)
     t.panel_w = 0;
+    t.panel_w8 = 0;
     for (int T0 = 0; T0 < t.ntiles; T0 += 16) {
         const int T1 = std::min(T0 + 15, t.ntiles - 1);
         t.panel_w = std::max(t.panel_w, t.kbase[T1] + KB * 64 - t.kbase[T0]);
     }
+    for (int T0 = 0; T0 < t.ntiles; T0 += 8) {
+        const int T1 = std::min(T0 + 7, t.ntiles - 1);
+        t.panel_w8 = std::max(t.panel_w8, t.kbase[T1] + KB * 64 - t.kbase[T0]);
+    }
     t.panel_w = round_up(t.panel_w, 16);
+    t.panel_w8 = round_up(t.panel_w8, 16);
     t.b.assign((size_t)t.ntiles * KB * 3 * 1024, 0);
     for (int T = 0; T < t.ntiles; T++)
         for (int nn = 0; nn < 16; nn++) {
@@ -698,24 +704,31 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
             const int nlines = pass == 0 ? ch_ : p.mmh.nout;
             static const int wpb = getenv("MRCHIP_MM_WPB") ? atoi(getenv("MRCHIP_MM_WPB")) : 16;
             static const int no_panel = getenv("MRCHIP_MM_NO_PANEL") ? 1 : 0;
-            const bool panel = !no_panel && M.kalign == 16 && M.panel_w <= 1024;
-            const int wg_tiles = panel ? PNW : wpb;
+            // 8 tiles per workgroup where their panel fits the 512 loader lanes (16 lines x 32 chunks of 16 bytes): two
+            // independent workgroups per CU instead of one of 16 waves (the kernel needs ~82 registers: 4-5 waves per
+            // SIMD either way) overlap their barrier / load / MFMA phases -- 128 pages 1.64 + 0.58 -> 1.41 + 0.55 ms
+            const bool panel8 = !no_panel && M.kalign == 16 && M.panel_w8 <= 512;
+            const bool panel = panel8 || (!no_panel && M.kalign == 16 && M.panel_w <= 1024);
+            const int nw = panel8 ? 8 : PNW;
+            const int wg_tiles = panel ? nw : wpb;
             const int gx = cdiv(M.ntiles, wg_tiles), gy = cdiv(cdiv(nlines, 64), qpw);
             const dim3 grid(round_up(gx * gy * npages, 8));
             const double a = (pass == 0 && !red) ? alg : 0.0;
             const char *nm = pass == 0 ? "thumb_resize_h" : "thumb_resize_v";
             const v4i *bt = reinterpret_cast<const v4i *>(tb + p.off_mm[pass][2]);
             if (panel) {
-                int pws = M.panel_w + 16;
+                const int pw = panel8 ? M.panel_w8 : M.panel_w;
+                int pws = pw + 16;
                 if (((pws >> 4) & 1) == 0) pws += 16;          // odd number of 16-byte units per row: conflict-free operand reads
-                const size_t lds = (size_t)2 * 16 * pws + (size_t)PNW * 16 * 80;
-#define MMP_LAUNCH(KBB)                                                                                                   \
+                const size_t lds = (size_t)2 * 16 * pws + (size_t)nw * 16 * 80;
+#define MMP_LAUNCH(KBB, NWW)                                                                                              \
     LAUNCH(ctx, s, nm, a,                                                                                                 \
-           hipLaunchKernelGGL((resize_mm_panel_kernel<KBB>), grid, dim3(64 * PNW), lds, s, in.p, in.pitch, in.stride, nlines, \
+           hipLaunchKernelGGL((resize_mm_panel_kernel<KBB, NWW>), grid, dim3(64 * NWW), lds, s, in.p, in.pitch, in.stride, nlines, \
                               out.p, out.pitch, out.stride, M.nout, M.ntiles, tptr(p.off_mm[pass][0]),                     \
-                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages, M.panel_w, pws,     \
+                              tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages, pw, pws,            \
                               pass == 0 ? cw * c : ch_))
-                if (M.KB == 1) MMP_LAUNCH(1); else MMP_LAUNCH(2);
+                if (panel8) { if (M.KB == 1) MMP_LAUNCH(1, 8); else MMP_LAUNCH(2, 8); }
+                else { if (M.KB == 1) MMP_LAUNCH(1, 16); else MMP_LAUNCH(2, 16); }
 #undef MMP_LAUNCH
                 continue;
             }

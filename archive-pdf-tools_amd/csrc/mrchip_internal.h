@@ -249,7 +249,7 @@ struct ThumbPlan {
     // (bias), and the MFMA B operand (KB blocks of 64 input bytes x 3 balanced base-256 digits of
     // the 22-bit coefficients, already in lane order).
     struct Mm {
-        int ntiles = 0, KB = 0, nout = 0, kalign = 1, panel_w = 0;   // panel_w: input bytes spanned by 16 consecutive tiles
+        int ntiles = 0, KB = 0, nout = 0, kalign = 1, panel_w = 0, panel_w8 = 0;   // panel_w / panel_w8: input bytes spanned by 16 / 8 consecutive tiles
         std::vector<int32_t> kbase, bias; std::vector<unsigned char> b;
     };
     Mm mmh, mmv;
