@@ -113,6 +113,67 @@ __global__ __launch_bounds__(256) void reduce_kernel(const uint8_t *src, int spi
     }
 }
 
+// The same for the factors thumbnails actually use (2..4 across), four output pixels per lane: the FX*4*C input bytes
+// of a row come in as FX*C aligned dwords (rows are 64-byte aligned and a lane's span is a multiple of 4 bytes), the
+// 4*C output bytes leave as C dwords.  Lanes whose four pixels do not all have FX whole columns (right edge) and images
+// with other factors take reduce_kernel's per-byte path.  The first version moved one byte per load: 0.6 TB/s, the
+// dominant kernel of the 8000x6000 configuration.
+template <int C, int FX>
+__global__ __launch_bounds__(256) void reduce4_kernel(const uint8_t *src, int spitch, size_t sstride, int w, int h, int fy,
+                                                      uint8_t *dst, int dpitch, size_t dstride, int ow, int oh) {
+    const int g = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;       // group of 4 output pixels
+    const int ox0 = 4 * g;
+    if (ox0 >= ow) return;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const int y0 = oy * fy, y1 = min(h, y0 + fy);
+    constexpr int NB = 4 * C, NDW = FX * C;
+    if (ox0 + 4 <= ow && (ox0 + 4) * FX <= w) {
+        unsigned acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) acc[j] = 0;
+        for (int yy = y0; yy < y1; yy++) {
+            const unsigned *rp = reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + (size_t)ox0 * FX * C);
+            unsigned d[NDW];
+#pragma unroll
+            for (int q = 0; q < NDW; q++) d[q] = rp[q];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int ch = 0; ch < C; ch++)
+#pragma unroll
+                    for (int i = 0; i < FX; i++) {
+                        const int b = (p * FX + i) * C + ch;                 // byte of the lane's span (compile-time)
+                        acc[p * C + ch] += (d[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                    }
+        }
+        const int cells = (y1 - y0) * FX;
+        const unsigned mult = reduce_multiplier(cells), amend = (unsigned)cells / 2;
+        unsigned o[C];
+#pragma unroll
+        for (int q = 0; q < C; q++) o[q] = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) o[j >> 2] |= (((acc[j] + amend) * mult) >> 24) << (8 * (j & 3));
+        // (the reduced image is tight -- rows of rw*C bytes -- so its dwords may sit at any byte address)
+        typedef unsigned __attribute__((aligned(1))) unsigned_unaligned;
+        unsigned_unaligned *op = reinterpret_cast<unsigned_unaligned *>(dst + (size_t)oy * dpitch + (size_t)ox0 * C);
+#pragma unroll
+        for (int q = 0; q < C; q++) op[q] = o[q];
+        return;
+    }
+    for (int ox = ox0; ox < min(ow, ox0 + 4); ox++) {                      // right edge: partial cells
+        const int x0 = ox * FX, x1 = min(w, x0 + FX);
+        const int cells = (y1 - y0) * (x1 - x0);
+        const unsigned mult = reduce_multiplier(cells), amend = (unsigned)cells / 2;
+        for (int ch = 0; ch < C; ch++) {
+            unsigned ss = 0;
+            for (int yy = y0; yy < y1; yy++)
+                for (int xx = x0; xx < x1; xx++) ss += src[(size_t)yy * spitch + (size_t)xx * C + ch];
+            dst[(size_t)oy * dpitch + (size_t)ox * C + ch] = (uint8_t)(((ss + amend) * mult) >> 24);
+        }
+    }
+}
+
 __device__ __forceinline__ uint8_t clip8(int v) {
     v >>= 22;
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
@@ -685,9 +746,22 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
     int cw = p.w, ch_ = p.h;
     const bool red = p.fx > 1 || p.fy > 1;
     if (red) {
-        LAUNCH(ctx, s, "thumb_reduce", alg,
-               hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(p.rw, 256), p.rh, npages), dim3(256), 0, s, cur.p, cur.pitch,
-                                  cur.stride, cw, ch_, c, p.fx, p.fy, scratch1.p, scratch1.pitch, scratch1.stride, p.rw, p.rh));
+        const dim3 g4(cdiv(cdiv(p.rw, 4), 256), p.rh, npages);
+#define RED4(CC, FXX)                                                                                                   \
+    LAUNCH(ctx, s, "thumb_reduce", alg,                                                                                 \
+           hipLaunchKernelGGL((reduce4_kernel<CC, FXX>), g4, dim3(256), 0, s, cur.p, cur.pitch, cur.stride, cw, ch_, p.fy, \
+                              scratch1.p, scratch1.pitch, scratch1.stride, p.rw, p.rh))
+        if (c == 3 && p.fx == 2) RED4(3, 2);
+        else if (c == 3 && p.fx == 3) RED4(3, 3);
+        else if (c == 3 && p.fx == 4) RED4(3, 4);
+        else if (c == 1 && p.fx == 2) RED4(1, 2);
+        else if (c == 1 && p.fx == 3) RED4(1, 3);
+        else if (c == 1 && p.fx == 4) RED4(1, 4);
+        else
+            LAUNCH(ctx, s, "thumb_reduce", alg,
+                   hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(p.rw, 256), p.rh, npages), dim3(256), 0, s, cur.p, cur.pitch,
+                                      cur.stride, cw, ch_, c, p.fx, p.fy, scratch1.p, scratch1.pitch, scratch1.stride, p.rw, p.rh));
+#undef RED4
         cur = scratch1; cw = p.rw; ch_ = p.rh;
     }
     const char *tb = reinterpret_cast<const char *>(d_tables);
