@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+E2E_BATCH, E2E_SLOTS = 8, 4        # decompose_stream's defaults: the setting that keeps both directions of the link busiest
 PCIE_SPEC_GBS = 63.0        # PCIe Gen5 x16 per direction (MI355X_MICROARCH.md)
 REFERENCE_PAGES_PER_S_PER_CORE = 0.33   # the reference itself on configs[1], BASELINE.md 2 (survey container, 1 core)
 
@@ -185,7 +186,7 @@ def main():
     ap.add_argument('--pages', type=int, default=None, help='pages per GPU per step (default: per config)')
     ap.add_argument('--inflight', type=int, default=None, help='device batches in flight per GPU (one HIP stream each)')
     ap.add_argument('--distinct', type=int, default=None, help='distinct synthetic pages per GPU, cycled through the batch')
-    ap.add_argument('--e2e-pages', type=int, default=256, help='pages per GPU pushed through the streaming pipeline (0: skip)')
+    ap.add_argument('--e2e-pages', type=int, default=512, help='pages per GPU pushed through the streaming pipeline (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (profiling runs)')
     a = ap.parse_args()
@@ -470,7 +471,21 @@ def link_rates(ctx):
         bt.download_layer(0, 0, size, out=pin, wait=False)
     bt.sync()
     out['d2h_GBps'] = round(4 * pin.nbytes / (time.perf_counter() - t) / 1e9, 1)
+    # both directions at once (a second batch = a second stream uploads while the first downloads): what a pipeline that
+    # moves pages in and results out at the same time can get from the link, each way
+    bt2 = mrc.Batch(ctx, 1, w, h, 3)
+    pin2 = ctx.pinned_empty((h, w, 3))
+    pin2[...] = 2
+    bt2.upload(0, pin2)
+    ctx.sync()
+    t = time.perf_counter()
+    for _ in range(4):
+        bt2.upload(0, pin2)
+        bt.download_layer(0, 0, size, out=pin, wait=False)
+    ctx.sync()
+    out['duplex_GBps_each_way'] = round(4 * pin.nbytes / (time.perf_counter() - t) / 1e9, 1)
     bt.close()
+    bt2.close()
     return out
 
 
@@ -493,14 +508,14 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
         else:
             src = [(img, hocr) for img, hocr, _ in host_pages]
         gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
-                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=32, mask_format='packed', pool=pool)
+                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool)
         warm = 0
         for _ in gen:                   # first pass also allocates the slots: run the stream twice, time the second
             warm += 1
         comm.barrier()
         phases = {}
         gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
-                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=32, mask_format='packed', pool=pool,
+                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool,
                                    stats=phases)
         t0 = time.perf_counter()
         n = 0
@@ -517,16 +532,20 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
                      'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}
     pool.close()
     best = max(res.values(), key=lambda r: r['pages_per_s'])
-    out = {'pages_per_s': best['pages_per_s'], 'pages_per_gpu': n_pages, 'batch_pages': 32, 'slots': 3,
+    out = {'pages_per_s': best['pages_per_s'], 'pages_per_gpu': n_pages, 'batch_pages': E2E_BATCH, 'slots': E2E_SLOTS,
            'host_arrays': res, 'bytes_in_per_page': W * H * Cc, 'bytes_out_per_page': out_bytes,
            'what': 'mrc.decompose_stream: host page arrays in (pageable numpy / page-locked), packed 1-bpp mask + fg + bg '
-                   'thumbnail out into page-locked arrays; upload, compute and download of three rotating batches overlap'}
+                   'thumbnail out into page-locked arrays; upload, compute and download of rotating batches overlap'}
     if link:
         out['link_measured'] = link
         out['link_spec_GBps_per_direction'] = PCIE_SPEC_GBS
         lim = min(link['h2d_GBps'] / (W * H * Cc / 1e9), link['d2h_GBps'] / (out_bytes / 1e9))
-        out['link_ceiling_pages_per_s_per_gpu'] = round(lim, 1)
+        out['link_ceiling_pages_per_s_per_gpu'] = round(lim, 1)           # each direction at the rate it reaches alone
         out['frac_of_link_ceiling'] = round(best['pages_per_s'] / world / lim, 3)
+        if link.get('duplex_GBps_each_way'):
+            dlim = link['duplex_GBps_each_way'] / (max(W * H * Cc, out_bytes) / 1e9)
+            out['duplex_ceiling_pages_per_s_per_gpu'] = round(dlim, 1)      # ... at the rate both reach when they run at once
+            out['frac_of_duplex_ceiling'] = round(best['pages_per_s'] / world / dlim, 3)
     return out
 
 
