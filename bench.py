@@ -584,7 +584,7 @@ def stack_check(ctx, comm, mrc, synth, cfg, rank, world):
     return {'pages': len(allrecs), 'distinct': len(seeds), 'all_pages_present': sorted(r['page'] for r in allrecs) == list(range(STACK_PAGES)),
             'mismatches': bad, 'seconds_incl_hashing': round(dt, 2),
             'what': '512-page stack sharded page i -> rank i mod N, per-page {page, rank, mask_popcount, sha256 x3} records '
-                    'gathered over RCCL and checked against the reference digests on rank 0'}
+                    'gathered over the control plane (config.control_plane) and checked against the reference digests on rank 0'}
 
 
 if __name__ == '__main__':
