@@ -191,15 +191,34 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const SigJob *jobs, size_
     __syncthreads();
     const U p0 = (U)st->prefix[0], p1 = (U)st->prefix[1];
     const unsigned mask = (1u << bits) - 1u;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        T v = dd[i];
-        if (v == (T)0) continue;
+    auto count = [&](T v) {
+        if (v == (T)0) return;
         U key = Key<T>::of(v);
         unsigned d = (unsigned)(key >> shift) & mask;
         U hi = (shift + bits >= Key<T>::BITS) ? (U)0 : (key >> (shift + bits));
         if (first || hi == p0) atomicAdd(&lh[0][d], 1u);
         if (first || hi == p1) atomicAdd(&lh[1][d], 1u);
+    };
+    // 16 bytes per lane and load (the pass is a plain read of the coefficients: one scalar load per iteration left
+    // every lane waiting for its own previous load, 2.4 TB/s), two loads in flight
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T v[V]; };
+    const Vec *dv = reinterpret_cast<const Vec *>(dd);            // dd starts 256-byte aligned in the scratch
+    const size_t nv = n / V, stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < nv; i += 2 * stride) {
+        const Vec a = dv[i], b = dv[i + stride];
+#pragma unroll
+        for (int k = 0; k < V; k++) count(a.v[k]);
+#pragma unroll
+        for (int k = 0; k < V; k++) count(b.v[k]);
     }
+    for (; i < nv; i += stride) {
+        const Vec a = dv[i];
+#pragma unroll
+        for (int k = 0; k < V; k++) count(a.v[k]);
+    }
+    for (size_t t = nv * V + (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride) count(dd[t]);
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * NBIN; i += 256) {
         unsigned c = (&lh[0][0])[i];
