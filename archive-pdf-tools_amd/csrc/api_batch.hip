@@ -54,6 +54,7 @@ struct mrchip_batch {
     std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
     hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
     int bits_valid = 0;                       // dn_bits holds the finished masks at 1 bpp (fast denoise ran)
+    bool commit_bits = false;                 // mask_finish in flight with the 1-bpp rows written by Sauvola + commit
     DevBuf packed;  int packed_valid = 0;     // 1-bpp copy of the finished masks (made on first request)
     size_t dn_stride = 0, th_bytes = 0;
     ThumbPlan plan[2];
@@ -123,6 +124,9 @@ static int batch_init(mrchip_batch *b, mrchip_ctx *ctx, int npages, int w, int h
     TRY(b->sig_scratch.alloc(ctx, b->sig_stride * npages));
     b->dn_stride = (denoise_scratch_bytes(w, h) + 3) / 4;
     TRY(b->dn_bits.alloc(ctx, b->dn_stride * 4 * npages));
+    // the 1-bpp rows' tails (bits past the last column inside a row's last word) must be zero and the fused producers
+    // (Sauvola, hOCR commit) never write there
+    HIP_TRY(hipMemsetAsync(b->dn_bits.p, 0, b->dn_stride * 4 * npages, b->s));
     b->page_boxes.resize(npages);
     b->gray_given.assign(npages, 0);
     b->sigma.assign(npages, 0.0);
@@ -295,6 +299,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
             hj[i].dst_inv = b->thB.as<uint8_t>() + 256 + bi.off + bi.phase;
             hj[i].dst_pitch = bi.pitch;
             hj[i].counts = dcounts + 2 * i;
+            hj[i].bits = nullptr; hj[i].bits_pitch = 0;
         }
         HIP_TRY(hipMemsetAsync(dcounts, 0, (size_t)nb * 8, s));
         HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nb * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
@@ -434,6 +439,10 @@ static int box_decisions_commit(mrchip_batch *b, int or_mode) {
         hb[i].mpitch = b->mask.pl.pitch;
         hb[i].page_end = b->first_box[bi.page + 1];
         hb[i].overlapped = 0;
+        hb[i].bits = (or_mode && b->commit_bits)
+                         ? reinterpret_cast<uint8_t *>(b->dn_bits.as<unsigned>() + (size_t)bi.page * b->dn_stride + (size_t)cdiv(b->w, 32) * b->h)
+                         : nullptr;
+        hb[i].bits_pitch = cdiv(b->w, 32) * 4;
         for (int j = i + 1; j < hb[i].page_end; j++) {
             const BoxInfo &bj = b->boxes[j];
             if (bj.decision && bj.l < bi.r && bi.l < bj.r && bj.t < bi.b && bi.t < bj.b) { hb[i].overlapped = 1; break; }
@@ -499,17 +508,28 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     }
     SauvolaJob *hj = reinterpret_cast<SauvolaJob *>(b->hctrl + L.pjobs);
     SauvolaJob *dj = reinterpret_cast<SauvolaJob *>(dctrl + L.pjobs);
+    // The denoiser works on 1-bpp rows.  Where the page launch takes the 8- / 16-column Sauvola kernel, that kernel and the
+    // box commit write those rows alongside the mask bytes (a byte per lane more; a 16-bit OR per lane), and the separate
+    // pass that re-read the whole byte mask to pack it is not run.
+    const int wpr = cdiv(w, 32);
+    static const bool no_fuse = getenv("MRCHIP_FUSED_PACK") && atoi(getenv("MRCHIP_FUSED_PACK")) == 0;
+    const bool fuse_bits = denoise_fast && !no_fuse && w > 4 && h > 4 && wpr <= 512 && sauvola_writes_bits(w, h, b->window);
+    b->commit_bits = fuse_bits;
     for (int i = 0; i < N; i++) {
         hj[i].src = thr_src.page(i); hj[i].src_pitch = thr_src.pitch;
         hj[i].w = w; hj[i].h = h;
         hj[i].dst = b->mask.pl.page(i); hj[i].dst_pitch = b->mask.pl.pitch;
         hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
+        // the denoiser's ORIGINAL rows: second half of the page's bit scratch
+        hj[i].bits = fuse_bits ? reinterpret_cast<uint8_t *>(b->dn_bits.as<unsigned>() + (size_t)i * b->dn_stride + (size_t)wpr * h) : nullptr;
+        hj[i].bits_pitch = wpr * 4;
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, b->window, b->window, 0.34, 128.0, SAUVOLA_INVERT));   // :325-329 (stored, not OR-ed)
     TRY(box_decisions_commit(b, 1));      // mrc.py:240-266 on top: mask = page threshold | box thresholds
+    b->commit_bits = false;
     if (denoise_fast)
-        TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N));  // :388
+        TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N, fuse_bits));  // :388
     b->state = 4;
     b->packed_valid = 0;
     // the denoiser's bit rows are the final mask when its bit-sliced path ran (launch_denoise_batch)
@@ -542,6 +562,7 @@ MRCHIP_EXPORT int mrchip_batch_threshold(mrchip_batch *b, int window, double k) 
         hj[i].w = b->w; hj[i].h = b->h;
         hj[i].dst = b->mask.pl.page(i); hj[i].dst_pitch = b->mask.pl.pitch;
         hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
+        hj[i].bits = nullptr; hj[i].bits_pitch = 0;
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, window, window, k, 128.0, SAUVOLA_INVERT));

@@ -487,17 +487,20 @@ static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, s
 
 size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) * 2 + 256; }
 
+// bits_ready: the original 1-bpp rows (second half of a page's scratch) already hold the mask -- the Sauvola page
+// launch and the hOCR commit wrote them alongside the bytes -- so `pack` is not run
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
-                         size_t bits_stride, int npages) {
+                         size_t bits_stride, int npages, bool bits_ready) {
     if (n < 0 || mincnt < 0) { set_error("denoise: negative parameter"); return MRCHIP_E_ARG; }
     if (w <= 2 * n || h <= 2 * n) return 0;      // empty inner rectangle: nothing changes
     const int wpr = cdiv(w, 32);
     const int pitch = mask.pitch;
     if (n == 2 && mincnt == 4 && wpr <= 64 * 8) {
         dim3 grid(cdiv(wpr, 256), h, npages);
-        LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h * npages,
-               hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask.p, pitch, mask.stride, w, h,
-                                  bits + (size_t)wpr * h, wpr, bits_stride));        // originals: second half of a page's scratch
+        if (!bits_ready)
+            LAUNCH(ctx, s, "denoise_pack", 1.0 * w * h * npages,
+                   hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, mask.p, pitch, mask.stride, w, h,
+                                      bits + (size_t)wpr * h, wpr, bits_stride));        // originals: second half of a page's scratch
         if (wpr <= 64) TRY(launch_seq<1>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, bits_stride, w, h, npages));

@@ -6,6 +6,9 @@
 
 namespace mrchip {
 
+// four 0/1 bytes -> four bits (byte k -> bit k)
+__device__ __forceinline__ unsigned nib01(unsigned x) { return ((x * 0x01020408u) >> 24) & 0xFu; }
+
 __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, int first, int or_mode) {
     const int b = first + blockIdx.z;
     const HocrBox B = boxes[b];
@@ -32,6 +35,12 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
                 v.x |= m.x; v.y |= m.y; v.z |= m.z; v.w |= m.w;
             }
             *reinterpret_cast<uint4 *>(mp) = v;
+            if (B.bits) {
+                // the same 16 pixels of the 1-bpp row: the lane owns the whole group and holds its final bytes (page
+                // threshold | box threshold), so it STORES the 16 bits -- no read-modify-write, no atomic
+                const unsigned m16 = nib01(v.x) | nib01(v.y) << 4 | nib01(v.z) << 8 | nib01(v.w) << 12;
+                *reinterpret_cast<unsigned short *>(B.bits + (size_t)py * B.bits_pitch + (xa0 >> 3)) = (unsigned short)m16;
+            }
             continue;
         }
 #pragma unroll
@@ -57,6 +66,13 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
                 }
             }
             if (!keep) continue;
+            if (B.bits) {         // partial group: another box may own other bits of the word -> atomic OR of the owned ones
+                unsigned tv = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if ((keep >> (8 * i)) & 0xffu) tv |= (unsigned)(tp[4 * q + i] & 1u) << i;
+                if (tv) atomicOr(reinterpret_cast<unsigned *>(B.bits + (size_t)py * B.bits_pitch) + (xa >> 5), tv << (xa & 31));
+            }
             uint8_t *mq8 = mp + 4 * q;
             if (keep == 0xffffffffu) {
                 const unsigned v = *reinterpret_cast<const unsigned *>(tp + 4 * q);

@@ -489,6 +489,19 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
             typedef unsigned __attribute__((address_space(1))) *g_u32p;
             g_u8p d = (g_u8p)(uintptr_t)(job.dst + (size_t)y * job.dst_pitch + c0);
             const bool aligned = (((uintptr_t)d) & 3u) == 0;
+            if constexpr (K >= 8) {
+                if (job.bits) {
+                    // the same pixels at 1 bit each (the denoiser's input rows: `pack` is not run): the lane's K columns
+                    // are K/8 whole bytes of the bit row -- strips start at multiples of 8 columns when bits are asked
+                    // for, so a byte has one owner; columns outside the image are zero in outa
+                    unsigned byte = 0;
+#pragma unroll
+                    for (int q = 0; q < KD; q++) byte |= (((outa[q] * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+                    g_u8p bp = (g_u8p)(uintptr_t)(job.bits + (size_t)y * job.bits_pitch + (c0 >> 3));
+                    if constexpr (K == 8) bp[0] = (uint8_t)byte;
+                    else *(unsigned short __attribute__((address_space(1))) *)bp = (unsigned short)byte;
+                }
+            }
             if (all && aligned) {
 #pragma unroll
                 for (int q = 0; q < KD; q++) ((g_u32p)d)[q] = outa[q];
@@ -581,6 +594,12 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
                     int njobs, SauvolaParams P, int maxw, int maxh, double alg_bytes) {
     constexpr int CW = 64 * K;
     P.two = (CW - P.ww - K) & ~3;
+    bool want_bits = false;
+    for (int i = 0; i < njobs; i++) want_bits = want_bits || h_jobs[i].bits != nullptr;
+    if (want_bits) {
+        if (K < 8) { set_error("sauvola: 1-bpp output needs the 8- or 16-column kernel (sauvola_writes_bits)"); return MRCHIP_E_ARG; }
+        P.two &= ~7;          // strips start at whole bytes of the bit rows
+    }
     if (P.two < 4) {
         set_error("sauvola: window width %d too large for the %d-column strip", P.ww, CW);
         return MRCHIP_E_UNSUPPORTED;
@@ -657,6 +676,16 @@ int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_b
     return 0;
 }
 
+// columns per lane of the kernel a launch takes
+static int sauvola_columns_per_lane(int maxw, int maxh, int ww) {
+    static const int force_k = getenv("MRCHIP_SAUVOLA_K") ? atoi(getenv("MRCHIP_SAUVOLA_K")) : 0;   // tuning knob
+    // 8 columns per lane halve the strip halo (452 of 512 columns are outputs instead of 200 of 256) at the
+    // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops
+    const bool page_like = maxw >= 1024 && maxh >= 256;
+    if (ww <= 120 && force_k != 8 && !(page_like && force_k != 4)) return 4;
+    return ww <= 360 ? 8 : 16;
+}
+
 // jobs: host array.  For njobs > 1 (or d_jobs != nullptr) the same array must
 // already be resident at d_jobs.
 int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, const SauvolaJob *d_jobs,
@@ -701,15 +730,13 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
             return MRCHIP_E_ARG;
         }
     }
-    static const int force_k = getenv("MRCHIP_SAUVOLA_K") ? atoi(getenv("MRCHIP_SAUVOLA_K")) : 0;   // tuning knob
-    // 8 columns per lane halve the strip halo (452 of 512 columns are outputs instead of 200 of 256) at the
-    // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops
-    const bool page_like = maxw >= 1024 && maxh >= 256;
-    if (ww <= 120 && force_k != 8 && !(page_like && force_k != 4))
-        return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
-    if (ww <= 360) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    const int K = sauvola_columns_per_lane(maxw, maxh, ww);
+    if (K == 4) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
+    if (K == 8) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     return launch_k<16>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
 }
+
+bool sauvola_writes_bits(int maxw, int maxh, int ww) { return sauvola_columns_per_lane(maxw, maxh, ww) >= 8; }
 
 int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
                    int ww, int wh, double k, double R, int flags) {

@@ -182,7 +182,14 @@ struct SauvolaJob {
     int dst_pitch;
     uint8_t *dst_inv;     // optional: output for the 255-p image (polarity B), same pitch
     unsigned int *counts; // optional: counts[0] += #ones(A), counts[1] += #ones(B)
+    // optional (page jobs on the 8- / 16-column kernels, see sauvola_writes_bits): polarity A also at 1 bit per pixel,
+    // bit k of byte j of a row = column 8 j + k -- the little-endian 32-pixel words of the denoiser's rows.  Bytes past
+    // ceil(w / 8) of a row are never written.
+    uint8_t *bits;
+    int bits_pitch;       // bytes per row of the bit plane
 };
+// true when launch_sauvola_dev will take a kernel that can fill SauvolaJob::bits for jobs of this size / window
+bool sauvola_writes_bits(int maxw, int maxh, int ww);
 
 enum SauvolaFlags {
     SAUVOLA_INVERT = 1,   // store 1 for dark (mrc.threshold_image polarity)
@@ -229,6 +236,8 @@ struct HocrBox {
     int mpitch;
     int page_end;            // index one past the last box of the same page
     int overlapped;          // a later box of the page with a decision intersects this one
+    uint8_t *bits;           // optional (or_mode): row 0 of the page's 1-bpp mask rows, OR-ed alongside the bytes
+    int bits_pitch;
 };
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
                        int or_mode);
@@ -287,7 +296,7 @@ int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, 
                           float *tmp, int tpitch, size_t tstride, int npages, int max_radius);
 // bits: page i at bits + i*bits_stride dwords
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
-                         size_t bits_stride, int npages);
+                         size_t bits_stride, int npages, bool bits_ready = false);
 size_t denoise_scratch_bytes(int w, int h);
 int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
 int optimise_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
