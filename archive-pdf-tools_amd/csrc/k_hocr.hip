@@ -22,6 +22,12 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
     if (xa0 >= B.r) return;
     const uint8_t *th = B.decision == 1 ? B.th : B.thi;
     const bool whole = xa0 >= B.l && xa0 + 16 <= B.r;
+    // global (not flat) accesses on the main path: the pointers come out of a record, so hipcc would emit flat_* (which
+    // also count on lgkmcnt and are the slower instruction)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) *gc_u4p;
+    typedef u32x4 __attribute__((address_space(1))) *g_u4p;
+    typedef unsigned short __attribute__((address_space(1))) *g_u16p;
     for (int y = blockIdx.y; y < bh; y += gridDim.y) {
         const int py = B.t + y;
         const uint8_t *tp = th + (ptrdiff_t)y * B.pitch + (xa0 - B.l);
@@ -29,17 +35,14 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
         if (whole && !B.overlapped) {
             // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel has
             // exactly one owner (box, lane), so the read-modify-write is race-free
-            uint4 v = *reinterpret_cast<const uint4 *>(tp);
-            if (or_mode) {
-                const uint4 m = *reinterpret_cast<const uint4 *>(mp);
-                v.x |= m.x; v.y |= m.y; v.z |= m.z; v.w |= m.w;
-            }
-            *reinterpret_cast<uint4 *>(mp) = v;
+            u32x4 v = *(gc_u4p)(uintptr_t)tp;
+            if (or_mode) v |= *(gc_u4p)(uintptr_t)mp;
+            *(g_u4p)(uintptr_t)mp = v;
             if (B.bits) {
                 // the same 16 pixels of the 1-bpp row: the lane owns the whole group and holds its final bytes (page
                 // threshold | box threshold), so it STORES the 16 bits -- no read-modify-write, no atomic
                 const unsigned m16 = nib01(v.x) | nib01(v.y) << 4 | nib01(v.z) << 8 | nib01(v.w) << 12;
-                *reinterpret_cast<unsigned short *>(B.bits + (size_t)py * B.bits_pitch + (xa0 >> 3)) = (unsigned short)m16;
+                *(g_u16p)(uintptr_t)(B.bits + (size_t)py * B.bits_pitch + (xa0 >> 3)) = (unsigned short)m16;
             }
             continue;
         }

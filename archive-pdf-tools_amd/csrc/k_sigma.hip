@@ -24,8 +24,11 @@ __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
 
+// (global, not flat: the pointers of these kernels come out of job records, for which hipcc emits the slower flat_*
+// instructions unless the address space is spelled out)
 typedef unsigned unsigned_a1 __attribute__((aligned(1)));
-__device__ __forceinline__ unsigned ld_u32(const uint8_t *p) { return *reinterpret_cast<const unsigned_a1 *>(p); }
+typedef const unsigned_a1 __attribute__((address_space(1))) *gc_u32a1_p;
+__device__ __forceinline__ unsigned ld_u32(const uint8_t *p) { return *(gc_u32a1_p)(uintptr_t)p; }
 
 template <class T>
 struct Db2 { T f[4]; };
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> 
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (m0 + q < w2) {
-                dd[(size_t)k * w2 + m0 + q] = out[q];
+                ((T __attribute__((address_space(1))) *)(uintptr_t)dd)[(size_t)k * w2 + m0 + q] = out[q];
                 if (out[q] != (T)0) atomicAdd(&lh[(unsigned)(Key<T>::of(out[q]) >> (Key<T>::BITS - DIG))], 1u);
             }
     }
@@ -202,21 +205,22 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const SigJob *jobs, size_
     // 16 bytes per lane and load (the pass is a plain read of the coefficients: one scalar load per iteration left
     // every lane waiting for its own previous load, 2.4 TB/s), two loads in flight
     constexpr int V = 16 / sizeof(T);
-    struct alignas(16) Vec { T v[V]; };
-    const Vec *dv = reinterpret_cast<const Vec *>(dd);            // dd starts 256-byte aligned in the scratch
+    typedef T Vec __attribute__((ext_vector_type(V)));
+    typedef const Vec __attribute__((address_space(1))) *gc_vec_p;
+    const gc_vec_p dv = (gc_vec_p)(uintptr_t)dd;                  // dd starts 256-byte aligned in the scratch
     const size_t nv = n / V, stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + stride < nv; i += 2 * stride) {
         const Vec a = dv[i], b = dv[i + stride];
 #pragma unroll
-        for (int k = 0; k < V; k++) count(a.v[k]);
+        for (int k = 0; k < V; k++) count(a[k]);
 #pragma unroll
-        for (int k = 0; k < V; k++) count(b.v[k]);
+        for (int k = 0; k < V; k++) count(b[k]);
     }
     for (; i < nv; i += stride) {
         const Vec a = dv[i];
 #pragma unroll
-        for (int k = 0; k < V; k++) count(a.v[k]);
+        for (int k = 0; k < V; k++) count(a[k]);
     }
     for (size_t t = nv * V + (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride) count(dd[t]);
     __syncthreads();
