@@ -17,7 +17,14 @@ def main():
     ap.add_argument('--pages', type=int, default=512)
     ap.add_argument('--combos', default='32x3,32x4,16x4,64x3,16x6')
     ap.add_argument('--mask', default='packed')
+    ap.add_argument('--node', type=int, default=-1, help='bind this process (and so its page-locked memory) to the CPUs of one NUMA node')
     a = ap.parse_args()
+    if a.node >= 0:
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % a.node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
     ctx = _lib.default_context()
     made = synth.synth_pages([dict(w=4000, h=3000, channels=3, seed=202 + i, noise_sigma=6.0, line_div=60) for i in range(8)])
     for combo in a.combos.split(','):
