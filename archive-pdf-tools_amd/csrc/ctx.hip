@@ -218,6 +218,23 @@ MRCHIP_EXPORT int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, 
     return 0;
 }
 
+// NUMA node of the host socket the context's GPU hangs off (from its PCI address in sysfs), -1 if unknown: a caller that
+// streams pages over PCIe wants its page-locked buffers -- and so the thread that allocates them -- on that node.
+MRCHIP_EXPORT int mrchip_device_numa_node(mrchip_ctx *ctx) {
+    if (!ctx) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) != hipSuccess) return -1;
+    for (char *p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells the address in lower case
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 MRCHIP_EXPORT int mrchip_prof_enable(mrchip_ctx *ctx, int enable) {
     if (!ctx) return MRCHIP_E_ARG;
     if (!enable) TRY(prof_resolve(ctx));

@@ -58,6 +58,7 @@ SIGNATURES = {
     'mrchip_page_download_mask_packed': (C.c_int, [vp, u8p]),
     'mrchip_page_layer': (C.c_int, [vp, C.c_int, C.c_double, intp, intp, intp]),
     'mrchip_page_layers': (C.c_int, [vp, C.c_double, C.c_double, intp, intp, intp, intp, intp]),
+    'mrchip_device_numa_node': (C.c_int, [vp]),
     'mrchip_page_download_layer': (C.c_int, [vp, C.c_int, u8p]),
     'mrchip_page_sync': (C.c_int, [vp]),
     'mrchip_page_box_decisions': (C.c_int, [vp, i32p, C.c_int]),
@@ -162,6 +163,10 @@ class Context:
 
     def sync(self):
         check(load().mrchip_sync(self.handle), 'mrchip_sync')
+
+    def numa_node(self):
+        """NUMA node of the socket the GPU is attached to, -1 if unknown."""
+        return int(load().mrchip_device_numa_node(self.handle))
 
     def info(self):
         name = C.create_string_buffer(128)

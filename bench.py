@@ -456,6 +456,15 @@ def _layer_size(w, h, ds):
     return (ow.value, oh.value)
 
 
+def _cpus_of_node(node):
+    cpus = set()
+    with open('/sys/devices/system/node/node%d/cpulist' % node) as f:
+        for part in f.read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
 def link_rates(ctx):
     """Measured PCIe rates of this GPU with page-locked host memory, one direction at a time (GB/s)."""
     import ctypes as C
@@ -508,6 +517,20 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     W, H, Cc = cfg['w'], cfg['h'], cfg['c']
     nd = len(host_pages)
     res = {}
+    # Host placement: the stream moves ~78 MB per page through page-locked host memory.  MRCHIP_BENCH_NUMA=1 binds this
+    # process to the CPUs of the NUMA node the GPU hangs off before anything page-locked is allocated; measured on three
+    # two-socket boxes of the pool (GPU on node 0 and on node 1) it made no difference (1 118 vs 1 118 pages/s), so the
+    # default leaves the affinity alone and only records where the GPU sits.  (The boxes on which the stream runs at
+    # ~810 pages/s are the ones whose link measures 53.6 instead of 56.9 GB/s outward.)
+    placement = {'gpu_numa_node': ctx.numa_node(), 'bound': False}
+    try:
+        if placement['gpu_numa_node'] >= 0 and os.environ.get('MRCHIP_BENCH_NUMA', '0') == '1':
+            cpus = _cpus_of_node(placement['gpu_numa_node'])
+            if cpus:
+                os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or cpus)
+                placement['bound'] = True
+    except Exception as e:          # noqa: BLE001 - placement is best effort
+        placement['error'] = str(e)
     link = link_rates(ctx) if rank == 0 else None
     pool = mrc.StreamPool(ctx)        # device batches + page-locked result arrays made once, as a long-running caller would
     for mode in ('pageable', 'pinned'):
@@ -545,6 +568,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     pool.close()
     best = max(res.values(), key=lambda r: r['pages_per_s'])
     out = {'pages_per_s': best['pages_per_s'], 'pages_per_gpu': n_pages, 'batch_pages': E2E_BATCH, 'slots': E2E_SLOTS,
+           'host_placement': placement,
            'host_arrays': res, 'bytes_in_per_page': W * H * Cc, 'bytes_out_per_page': out_bytes,
            'what': 'mrc.decompose_stream: host page arrays in (pageable numpy / page-locked), packed 1-bpp mask + fg + bg '
                    'thumbnail out into page-locked arrays; upload, compute and download of rotating batches overlap'}

@@ -56,6 +56,9 @@ const char *mrchip_last_error(void);
 int mrchip_sync(mrchip_ctx *ctx);
 /* Device name / CU count of the context's device (for reports). */
 int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes);
+/* NUMA node of the host socket this context's GPU is attached to (sysfs), -1 if unknown: where a streaming caller
+ * wants its page-locked buffers (mrchip_host_alloc from a thread running there). */
+int mrchip_device_numa_node(mrchip_ctx *ctx);
 
 /* Page-locked host memory for buffers handed to the *_async entry points (NULL on failure). */
 void *mrchip_host_alloc(mrchip_ctx *ctx, size_t bytes);
