@@ -770,12 +770,15 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
     const int32_t *d_khT = tptr(p.off_khT);
     if (p.mm_ok) {
         // horizontal: lines = image rows -> scratch2 transposed [output byte][row]; vertical: lines = those -> dst
-        const int qpw = npages >= 16 ? 8 : 2;              // quads of 64 lines per wave
+        static const int qpw_env = getenv("MRCHIP_MM_QPW") ? atoi(getenv("MRCHIP_MM_QPW")) : 0;      // tuning knob
+        // (quads of 64 lines per wave: chosen per pass below)
         const ThumbPlan::Mm *mm[2] = {&p.mmh, &p.mmv};
         for (int pass = 0; pass < 2; pass++) {
             const ThumbPlan::Mm &M = *mm[pass];
             const Plane in = pass == 0 ? cur : scratch2, out = pass == 0 ? scratch2 : dst;
             const int nlines = pass == 0 ? ch_ : p.mmh.nout;
+            // lines per wave: the horizontal pass (image rows are its lines) likes longer runs than the vertical one
+            const int qpw = qpw_env > 0 ? (pass == 0 ? qpw_env : 8) : (npages >= 16 ? (pass == 0 ? 16 : 8) : 2);
             static const int wpb = getenv("MRCHIP_MM_WPB") ? atoi(getenv("MRCHIP_MM_WPB")) : 16;
             static const int no_panel = getenv("MRCHIP_MM_NO_PANEL") ? 1 : 0;
             // 8 tiles per workgroup where their panel fits the 512 loader lanes (16 lines x 32 chunks of 16 bytes): two
