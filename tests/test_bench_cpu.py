@@ -1,0 +1,46 @@
+"""CPU suite: the parts of bench.py that need no GPU -- the build stamp, the provenance-checked traffic figures it
+quotes from the committed PMC passes, the streaming defaults it reports."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_traffic_of_both_roofline_kernels_comes_from_the_committed_profile():
+    import bench
+    for name, alg in (('optimise_rgb', 21.504e9), ('sauvola', 3.072e9)):
+        traffic, src = bench.pmc_traffic(name, alg)
+        assert src and src['file'].startswith('profiles/') and src['profiled_head'], (name, src)
+        # every image row is read three times and written once: traffic is above the algorithmic bytes, well below 4x
+        assert traffic is not None and alg < traffic < 4 * alg, (name, traffic, alg)
+
+
+def test_committed_bench_lines_have_the_contract_fields():
+    for cfg in ('c2', 'c3', 'c3gray', 'c5'):
+        with open(os.path.join(ROOT, 'profiles', 'r02_bench_%s.json' % cfg)) as f:
+            d = json.load(f)
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                    'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+            assert key in d, (cfg, key)
+        assert d['vs_baseline'] is None and d['dtype'] == 'u8' and 'workload' in d['config']
+        r = d['roofline']
+        assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4
+        assert d['parity']['mismatches'] == 0
+    with open(os.path.join(ROOT, 'profiles', 'r02_bench_c2.json')) as f:
+        c2 = json.load(f)
+    assert c2['cpu_baseline']['kind'] == 'port' and c2['cpu_baseline']['cores'] >= 1
+    assert c2['roofline']['kernel'] == 'optimise_rgb'            # ranked in the isolated pass, not by overlapped HIP events
+    assert c2['config4_stack']['mismatches'] == 0 and c2['config4_stack']['all_pages_present']
+
+
+def test_build_stamp_and_stream_defaults():
+    import bench
+    head = bench.git_head()
+    assert head and len(head.rstrip('+')) >= 7
+    sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
+    import inspect
+    from mrchip import mrc
+    sig = inspect.signature(mrc.decompose_stream)
+    assert (sig.parameters['batch_pages'].default, sig.parameters['slots'].default) == (bench.E2E_BATCH, bench.E2E_SLOTS)
