@@ -641,7 +641,7 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
 
 
 def decompose_pages(images, hocr_list, dpi=None, downsample=None, bg_downsample=None, fg_downsample=None,
-                    denoise_mask=DENOISE_FAST, ctx=None, batch_pages=32, max_batch_bytes=None):
+                    denoise_mask=DENOISE_FAST, ctx=None, batch_pages=8, max_batch_bytes=None):
     """Batch form of create_mrc_hocr_components: the list of (mask, fg, bg) tuples the generator would yield
     page by page, in input order (arrays owned by the caller).  Pages of different sizes / modes may be mixed:
     consecutive pages of one geometry share a device batch (decompose_stream does the work)."""
