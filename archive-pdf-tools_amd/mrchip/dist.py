@@ -71,10 +71,34 @@ class SoloComm(_Comm):
         return float(value)
 
 
+class _stdout_to_stderr:
+    """fd 1 -> fd 2 for the duration of the block (native code that prints on stdout), restored on exit"""
+
+    def __init__(self, on=True):
+        self.on, self.saved = on, None
+
+    def __enter__(self):
+        if self.on:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+        return False
+
+
 class RcclComm(_Comm):
     """RCCL through libmrchip (mrchip_comm_*).  `ctx`: the rank's mrchip Context (its device is the rank's GPU)."""
 
-    def __init__(self, ctx, rank, world, rendezvous=None, timeout=120.0):
+    def __init__(self, ctx, rank, world, rendezvous=None, timeout=120.0, redirect_stdout=True):
+        """redirect_stdout: point fd 1 at stderr around the two RCCL calls that print a banner.  Only for a caller that
+        runs this constructor synchronously: make_comm() runs it on a helper thread that may never return, so it does
+        the redirection itself (around the join, restored unconditionally) and passes False."""
         from . import _lib
         self._lib = _lib
         self.lib = _lib.load()
@@ -82,14 +106,8 @@ class RcclComm(_Comm):
         path = rendezvous or rendezvous_path()
         ident = (C.c_uint8 * 128)()
         if rank == 0:
-            sys.stdout.flush()
-            saved = os.dup(1)
-            try:
-                os.dup2(2, 1)
+            with _stdout_to_stderr(redirect_stdout):
                 _lib.check(self.lib.mrchip_comm_unique_id(ident), 'mrchip_comm_unique_id')
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
             tmp = path + '.tmp'
             with open(tmp, 'wb') as f:
                 f.write(bytes(ident))
@@ -104,14 +122,8 @@ class RcclComm(_Comm):
                 raw = f.read()
             C.memmove(ident, raw, 128)
         # RCCL prints a version banner on stdout when a communicator is made; a benchmark's stdout is its result line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        try:
-            os.dup2(2, 1)
+        with _stdout_to_stderr(redirect_stdout):
             self._h = self.lib.mrchip_comm_init(ctx.handle, rank, world, ident)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
         if not self._h:
             raise _lib.MrchipError('mrchip_comm_init: %s' % _lib.last_error())
         self._path = path
@@ -213,32 +225,48 @@ class FileComm(_Comm):
         self._exchange(b'', [])     # (removes them; the 8-byte files of the last barrier stay behind)
 
 
-def make_comm(ctx, rank, world, timeout=90.0):
+class RcclUnavailable(RuntimeError):
+    """MRCHIP_REQUIRE_RCCL=1 and RCCL did not come up on every rank"""
+
+
+def make_comm(ctx, rank, world, timeout=90.0, comm_factory=None):
     """The control-plane transport of a multi-rank run: RCCL if every rank gets its communicator, else files.
     ncclCommInitRank blocks until all ranks have joined and cannot be cancelled, so it runs on a helper thread with a
     deadline; the ranks then tell each other (through files) whether it returned, and only if it did everywhere is the
-    RCCL communicator used.  Returns (comm, description)."""
+    RCCL communicator used.  Returns (comm, description); the description starts with 'rccl' only when RCCL carries
+    the control plane.  The fallback is never silent: it is written to stderr, and with MRCHIP_REQUIRE_RCCL=1 it raises
+    RcclUnavailable instead (after the ranks have agreed, so all of them raise).
+    comm_factory: stands in for RcclComm in the CPU tests (a stub whose init blocks, or fails)."""
     if world == 1:
         return SoloComm(), 'none (one rank)'
     fc = FileComm(rank, world)
     import threading
     box = {}
+    factory = comm_factory or (lambda: RcclComm(ctx, rank, world, redirect_stdout=False))
 
     def init():
         try:
-            box['comm'] = RcclComm(ctx, rank, world)
+            box['comm'] = factory()
         except Exception as e:          # noqa: BLE001 - any failure means "no RCCL on this rank"
             box['err'] = '%s: %s' % (type(e).__name__, e)
 
+    # RCCL prints a banner on stdout while the communicator is made; a benchmark's stdout is its result line.  The
+    # redirection is process-wide, so it is made and undone HERE, around the join: a helper thread stuck in
+    # ncclCommInitRank never reaches a `finally` of its own, and fd 1 would stay on stderr for the rest of the run.
     th = threading.Thread(target=init, daemon=True)
-    th.start()
-    th.join(timeout)
+    with _stdout_to_stderr(True):
+        th.start()
+        th.join(timeout)
     ok = 'comm' in box
     flags = fc.allgather_obj({'ok': ok, 'err': box.get('err', 'ncclCommInitRank did not return within %.0f s' % timeout if not ok else '')})
     if all(f['ok'] for f in flags):
         fc.close()
         return box['comm'], 'rccl'
     why = '; '.join('rank %d: %s' % (i, f['err']) for i, f in enumerate(flags) if not f['ok'])
+    if os.environ.get('MRCHIP_REQUIRE_RCCL', '') not in ('', '0'):
+        raise RcclUnavailable('MRCHIP_REQUIRE_RCCL is set and RCCL did not come up on every rank -- %s' % why)
+    sys.stderr.write('mrchip.dist: rank %d: RCCL UNAVAILABLE, control plane falls back to files -- %s\n' % (rank, why))
+    sys.stderr.flush()
     return fc, 'files (RCCL unavailable -- %s)' % why
 
 

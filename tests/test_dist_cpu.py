@@ -131,3 +131,57 @@ def test_file_comm_three_ranks(tmp_path):
 def test_make_comm_falls_back_to_files_when_rccl_cannot_start(tmp_path):
     how = _run_file_ranks(tmp_path, 2, 'auto')['how']
     assert how.startswith('files (RCCL unavailable'), how
+
+
+BLOCK_WORKER = textwrap.dedent('''
+    import os, sys, json, threading
+    sys.path.insert(0, os.path.join(%r, 'archive-pdf-tools_amd'))
+    from mrchip import dist as mdist
+    rank, world, base, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ['MRCHIP_RENDEZVOUS'] = base
+    if mode == 'require':
+        os.environ['MRCHIP_REQUIRE_RCCL'] = '1'
+    class Ctx: handle = None
+    def stuck():                     # what ncclCommInitRank does when a peer never joins: prints, then never returns
+        os.write(1, b'RCCL banner on fd 1\\n')
+        threading.Event().wait()
+    try:
+        comm, how = mdist.make_comm(Ctx(), rank, world, timeout=2, comm_factory=stuck)
+    except mdist.RcclUnavailable as e:
+        print(json.dumps({'raised': str(e)}))
+        sys.exit(3)
+    comm.barrier()
+    print(json.dumps({'how': how, 'rank': rank}))        # the result line must still reach the real stdout
+    sys.stdout.flush()
+    os._exit(0)                      # the stuck helper thread is a daemon; leave without joining it
+''')
+
+
+def _run_block_ranks(tmp_path, mode):
+    script = tmp_path / 'bworker.py'
+    script.write_text(BLOCK_WORKER % ROOT)
+    base = str(tmp_path / 'bc')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', base, mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    return procs, [p.communicate(timeout=120) for p in procs]
+
+
+def test_make_comm_keeps_stdout_when_rccl_init_never_returns(tmp_path):
+    """ADVICE r2: the helper thread stuck in ncclCommInitRank must not leave fd 1 pointing at stderr."""
+    import json
+    procs, outs = _run_block_ranks(tmp_path, 'auto')
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, se[-2000:]
+        lines = [l for l in so.splitlines() if l.startswith('{')]
+        assert lines, 'rank %d: result line missing from stdout; stderr: %s' % (r, se[-500:])
+        out = json.loads(lines[-1])
+        assert out['how'].startswith('files (RCCL unavailable') and 'did not return' in out['how']
+        assert 'RCCL banner' not in so and 'RCCL banner' in se          # the banner went to stderr, the result did not
+        assert 'RCCL UNAVAILABLE' in se                                  # and the fallback is loud
+
+
+def test_make_comm_require_rccl_raises_on_every_rank(tmp_path):
+    procs, outs = _run_block_ranks(tmp_path, 'require')
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 3, (so, se[-1000:])
+        assert 'MRCHIP_REQUIRE_RCCL' in so
