@@ -695,8 +695,7 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
                     for (int i = i0; i < i0 + blk; i++) hj[k++] = tmp[Lr * N + i];
         }
     }
-    HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(OptJob), hipMemcpyHostToDevice, s));
-    TRY(launch_optimise_jobs(ctx, s, dj, nj, w, h, c, nmax, &b->opt_mail));
+    TRY(launch_optimise_jobs(ctx, s, hj, dj, nj, w, h, c, nmax, &b->opt_mail));      // (uploads the job records)
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
         if (b->layer_small[Lr])
@@ -747,14 +746,17 @@ static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *ou
     } else {
         TRY(download_2d(b->s, out, b->w * c, b->layer[Lr].pl.page(page), b->layer[Lr].pl.pitch, b->w * c, b->h));
     }
-    if (wait) HIP_TRY(hipStreamSynchronize(b->s));
+    if (wait) {
+        HIP_TRY(hipStreamSynchronize(b->s));
+        TRY(optmail_check(&b->opt_mail));          // a strip hand-off of optimise timed out: the layer is not valid
+    }
     return 0;
 }
 
 MRCHIP_EXPORT int mrchip_batch_sync(mrchip_batch *b) {
     CHECK_B(b);
     HIP_TRY(hipStreamSynchronize(b->s));
-    return 0;
+    return optmail_check(&b->opt_mail);
 }
 
 MRCHIP_EXPORT int mrchip_batch_box_decisions(mrchip_batch *b, int page, int32_t *decisions, int nb) {

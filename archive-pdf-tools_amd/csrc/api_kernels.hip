@@ -124,13 +124,12 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
     TRY(upload_2d(s, i.p, i.pitch, img, w * channels, w * channels, h));
     OptJob job = {m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, n_size, invert_mask ? 1 : 0};
-    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
-    OptMail mail;
-    TRY(launch_optimise_jobs(ctx, s, jb.as<OptJob>(), 1, w, h, channels, n_size, &mail));
+    job.mbits = nullptr; job.mwpr = 0;
+    OptMail mail;                          // (declared before the launch: its buffers outlive the kernels, see below)
+    TRY(launch_optimise_jobs(ctx, s, &job, jb.as<OptJob>(), 1, w, h, channels, n_size, &mail));
     TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));
-    HIP_TRY(hipStreamSynchronize(s));
-    return 0;
+    HIP_TRY(hipStreamSynchronize(s));      // `job` and `mail` live on this stack frame
+    return optmail_check(&mail);
 }
 
 MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int stride, int w, int h, int kind,

@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *mask, int
     bits[(size_t)y * wpr + j] = word;
 }
 
+int launch_pack_bits(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int pitch, int w, int h, unsigned *bits, int wpr) {
+    if (w <= 0 || h <= 0) return 0;
+    if (h > MAX_GRID_Z) { set_error("pack_bits: %d rows", h); return MRCHIP_E_UNSUPPORTED; }
+    LAUNCH(ctx, s, "mask_pack_bits", 1.125 * w * h,
+           hipLaunchKernelGGL(pack_bits_kernel, dim3(cdiv(wpr, 256), h, 1), dim3(256), 0, s, mask, pitch, (size_t)0, w, h, bits,
+                              wpr, (size_t)0));
+    return 0;
+}
+
 // 1 bit per pixel, most significant bit first, rows padded to whole bytes: the layout of a raw PBM
 // (P4) body and of PIL's mode '1' -- what mrc.encode_mrc_mask (mrc.py:474-520) turns the bool mask
 // into before it goes to jbig2/PNG.  One thread per output byte (8 mask bytes in).

@@ -630,7 +630,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                         __builtin_amdgcn_s_sleep(4);
                         RS.mbp = mail_load(mail_in + (size_t)(y - 1) * 4);
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(RS.mbp) : : "memory");
-                        if (++spins > (1 << 21)) { if (t == 0) *SI.err = 1u; break; }
+                        if (++spins > (1 << 21)) { if (t == 0) __hip_atomic_store(SI.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     }
                     if (lhalo) {
                         prev[0] = RS.mbp.x; if constexpr (ND > 1) prev[1] = RS.mbp.y; if constexpr (ND > 2) prev[2] = RS.mbp.z;
@@ -1195,8 +1195,8 @@ static int try_strips(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int 
     }
     mail->epoch++;
     StripInfo SI;
-    SI.S = S; SI.sw = sw; SI.mail = mail->buf.as<u32x4>() + 16;           // first 256 bytes: the error word
-    SI.tagbase = mail->epoch << 16; SI.err = mail->buf.as<unsigned>();
+    SI.S = S; SI.sw = sw; SI.mail = mail->buf.as<u32x4>() + 16;           // (first 256 bytes: unused)
+    SI.tagbase = mail->epoch << 16; SI.err = mail->err;                   // page-locked host word, see optmail_check
     const int nent = T * 4 + 2 * n_max;
     const size_t lds = (T <= 512 ? 2 : 1) * (size_t)(nent + nent / 4 + 1) * ((c == 3) ? 16 : 8);       // <= 512 threads: double-buffered rows
     const char *nm = c == 3 ? "optimise_rgb" : "optimise_gray";
@@ -1218,10 +1218,63 @@ static int try_strips(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int 
     return 1;
 }
 
-int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max,
-                         OptMail *mail) {
+OptMail::~OptMail() {
+    if (err) (void)hipHostFree(err);
+}
+
+int optmail_check(OptMail *mail) {
+    if (!mail || !mail->err) return 0;
+    const unsigned e = *reinterpret_cast<volatile unsigned *>(mail->err);
+    if (e) {
+        *reinterpret_cast<volatile unsigned *>(mail->err) = 0;
+        set_error("optimise: a strip gave up waiting for its left-hand neighbour's rows (hand-off timeout); the layers of this launch are invalid");
+        return MRCHIP_E_HIP;
+    }
+    return 0;
+}
+
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
+                         int n_max, OptMail *mail) {
     if (c != 1 && c != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
     if (w <= 0 || h <= 0 || njobs <= 0) return 0;
+    if (!mail) { set_error("optimise: no hand-off buffer"); return MRCHIP_E_ARG; }
+    if (!mail->err) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&mail->err), 64, hipHostMallocMapped));
+        *mail->err = 0;
+    }
+    int n_min = n_max;
+    for (int i = 0; i < njobs; i++) n_min = std::min(n_min, h_jobs[i].n);
+    const double alg_all = (1.0 + 2.0 * c) * w * h * njobs;
+    if (ws_supported(w, h, n_max, n_min)) {
+        // the wave-strip schedule reads the mask at 1 bit per pixel: callers that only have bytes get a packed copy
+        const int wpr = cdiv(w, 32);
+        const size_t per = (size_t)wpr * h * sizeof(unsigned);
+        size_t missing = 0;
+        for (int i = 0; i < njobs; i++) if (!h_jobs[i].mbits) missing++;
+        if (missing) {
+            if (mail->bits_bytes < missing * per) {
+                HIP_TRY(hipStreamSynchronize(s));
+                TRY(mail->bits.alloc(ctx, missing * per));
+                mail->bits_bytes = missing * per;
+            }
+            size_t k = 0;
+            for (int i = 0; i < njobs; i++) {
+                OptJob &j = h_jobs[i];
+                if (j.mbits) continue;
+                // jobs that share a byte mask (fg and bg of one page) share the packed copy
+                unsigned *dst = nullptr;
+                for (int q = 0; q < i && !dst; q++)
+                    if (h_jobs[q].mask == j.mask && h_jobs[q].mpitch == j.mpitch) dst = const_cast<unsigned *>(h_jobs[q].mbits);
+                if (!dst) {
+                    dst = reinterpret_cast<unsigned *>(mail->bits.as<unsigned char>() + (k++) * per);
+                    TRY(launch_pack_bits(ctx, s, j.mask, j.mpitch, w, h, dst, wpr));
+                }
+                j.mbits = dst; j.mwpr = wpr;
+            }
+        }
+        return launch_optimise_ws(ctx, s, h_jobs, d_jobs, njobs, w, h, c, mail, alg_all);
+    }
+    HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
     {
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
         if (st != 0) return st < 0 ? st : 0;

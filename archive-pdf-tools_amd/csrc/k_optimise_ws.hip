@@ -1,0 +1,569 @@
+// optimise_gray2 / optimise_rgb2 (reference: cython/optimiser.pyx:153-273, 280-429) for gfx950 -- the wave-strip
+// schedule.  Semantics and arithmetic as in k_optimise.hip (same packed 16-bit column sums, same exact quotient); what
+// differs is who walks the rows.
+//
+// The causal window of optimise looks LEFT and UP only: pixel (y, x) needs outputs of rows y-n .. y-1, columns
+// x-n .. x-1, never of its own row (pyx:213-220, 250-255).  So a page-layer is cut into column strips of ONE WAVE each
+// (<= 62 lanes x 4 columns of core, plus halo lanes on both sides), every wave walks its strip top to bottom at its own
+// pace, and the only thing that crosses a strip boundary is, per finished row, the n output columns at the boundary:
+// one 16-byte granule per 4 columns {12 bytes of output, tag}, written write-through (`sc0 sc1`) by the left strip's
+// last lanes and read `sc0 sc1` by the right strip's left-halo lanes (MI355X_MICROARCH.md, inter-workgroup
+// visibility: a data-tagged granule needs no fence and no flag, wherever the two waves run).  There is no workgroup
+// barrier anywhere: a wave that waits (for memory, for its neighbour) leaves the SIMD to the other waves resident
+// there, which belong to other strips, other page-layers, fg (n = 3) and bg (n = 10) alike -- the whole launch is one
+// pool of independent waves, and the chip is full as long as there are more strips than wave slots.
+// Whole rows on one 1024-thread workgroup (k_optimise.hip) spent a third of the time in the per-row chain
+// publish -> barrier -> window reads with the VALU idle (round 2: 64 % busy).
+//
+//  * halo: lanes left of the core rebuild the vertical FIR sums of the neighbour's last columns from the inputs and get
+//    the vertical IIR sums of those columns from the granules; lanes right of the core need FIR sums only.
+//    HL = ceil(n / 4) lanes on the left, HR = ceil((n - 1) / 4) on the right.
+//  * the horizontal windows slide over two wave-private LDS rows (entries of the 256 columns of the wave): LDS
+//    operations of one wave execute in order, so there is no wait between publish and window reads either.
+//  * the 1-bpp mask is loaded ONCE per row (the entering row); the lane's nibble goes into a shift register of
+//    2n + 1 nibbles from which the current and the leaving row's selection come out again.
+//  * dispatch order = (page-layer, strip), left strips first: a consumer is never resident without its producer
+//    having been dispatched, so the polls always end; they are bounded all the same and a timeout is reported
+//    (OptMail error word, checked by the host at the next synchronisation point).
+//
+// Algorithmic bytes: (1 + 2C) * w * h per call.
+#include <cstdlib>
+
+#include "mrchip_internal.h"
+
+namespace mrchip {
+
+typedef const unsigned __attribute__((address_space(1))) *gc_u32p;
+typedef unsigned __attribute__((address_space(1))) *g_u32p;
+typedef uint8_t __attribute__((address_space(1))) *g_u8p;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WsLaunch {
+    u32x4 *mail;            // granules; a job's part starts at OptJob::ws_mail
+    unsigned tagbase;       // epoch << 16
+    unsigned *err;          // page-locked host word, set when a poll gave up
+    int smax;               // grid = jobs * smax single-wave workgroups
+};
+
+__device__ __forceinline__ u32x4 ws_mail_load(const u32x4 *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ws_mail_store(u32x4 *p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+// 16-bit halves added straight out of the packed pairs (SDWA operand selects)
+__device__ __forceinline__ unsigned ws_add_w0w0(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned ws_add_w1w1(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned ws_add_dw0(unsigned a, unsigned b) {      // a + (b & 0xffff)
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned ws_add_dw1(unsigned a, unsigned b) {      // a + (b >> 16)
+    unsigned r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// NCT: n_size as a compile-time constant (3 and 10, the reference's two call sites mrc.py:413/415, 447/449) or -1 for
+// a run-time n <= 11.  16-bit lane capacity as in k_optimise.hip: one FIR accumulator up to n = 8 (and FIR + IIR in one
+// for n <= 7), two half-window accumulators up to n = 11.
+template <int C, int NCT>
+__device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const WsLaunch &L, const int strip) {
+    constexpr int P = 4;
+    constexpr int EW = (C == 3) ? 2 : 1;          // dwords per LDS entry
+    constexpr int ND = C;                          // dwords of pixel bytes per lane-row (P * C / 4)
+    constexpr bool SUMROW = (NCT >= 1 && NCT <= 7);
+    constexpr int NH = (NCT >= 0 && NCT <= 8) ? 1 : 2;
+    constexpr int HWORDS = NCT >= 0 ? (4 * (2 * NCT + 1) + 31) / 32 : 3;      // mask shift register, 2n + 1 nibbles
+    const uint8_t *__restrict__ img = J.img;
+    uint8_t *out = J.out;
+    const unsigned *mbits = J.mbits;
+    const int ipitch = J.ipitch, opitch = J.opitch, mwpr = J.mwpr, w = J.w, h = J.h;
+    const int n = NCT >= 0 ? NCT : J.n;
+    const int HL = (n + 3) >> 2, HR = (n + 2) >> 2;
+    const int l = threadIdx.x;
+    const int XS = strip * J.ws_clb * 4;          // first core column
+    const int XEc = XS + J.ws_clb * 4;            // one past the last core column (may lie beyond w in the last strip)
+    const int XE = min(w, XEc);
+    const int x0 = XS - 4 * HL + 4 * l;           // the lane's first column (may be < 0 or >= w)
+    const bool act = x0 >= XS && x0 < XE;
+    const bool lhalo = strip > 0 && l < HL;
+    const bool producer = strip + 1 < J.ws_S && x0 >= XEc - 4 * HL && x0 < XEc;
+    (void)HR;
+
+    // column the unconditional row loads use: clamped into the image, so that lanes outside (left of column 0, right of
+    // the last column group) read valid memory; their bytes are masked where they are used
+    const int xl = min(max(x0, 0), max(0, ((w - 1) / P) * P));
+    unsigned vo_px = (unsigned)(xl * C);
+    unsigned vo_m = (unsigned)((xl >> 5) * 4);
+    const unsigned msh = (unsigned)xl & 31u;
+    unsigned colm = 0, coln = 0, pxm[ND];          // 0xFF per valid column / bit per valid column / 0xFF per valid pixel byte
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if (x0 + b >= 0 && x0 + b < w) { colm |= 0xffu << (8 * b); coln |= 1u << b; }
+#pragma unroll
+    for (int q = 0; q < ND; q++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int cc = x0 + (4 * q + b) / C; if (cc >= 0 && cc < w) m |= 0xffu << (8 * b); }
+        pxm[q] = m;
+    }
+    const unsigned invn = J.invert ? 0xFu : 0u;
+
+    // wave-private LDS rows: entry of column x0 + j (j in [-n, 4 + n)) at lane base + (d + d / 4) * EW, d = j + n
+    const int npad = n;
+    const int nent = 64 * P + 2 * npad;
+    const int nelem = nent + nent / P + 1;
+    unsigned *firA = lds, *iirA = lds + (size_t)nelem * EW;
+    for (int i = l; i < 2 * nelem * EW; i += 64) lds[i] = 0;
+    const int ebase = 5 * l * EW;
+    auto eidx = [&](int j) { const int d = j + npad; return ebase + (d + (d >> 2)) * EW; };
+
+    struct Ent { unsigned d[EW]; };
+    auto eadd = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] += b.d[k];
+    };
+    auto esub = [](Ent &a, const Ent &b) {
+#pragma unroll
+        for (int k = 0; k < EW; k++) a.d[k] -= b.d[k];
+    };
+    auto lds_ld = [&](const unsigned *A, int j) {
+        Ent e;
+        const unsigned *p = A + eidx(j);
+        if constexpr (EW == 2) { uint2 v = *reinterpret_cast<const uint2 *>(p); e.d[0] = v.x; e.d[1] = v.y; }
+        else e.d[0] = p[0];
+        return e;
+    };
+
+    // mailbox slots of this strip's two boundaries (granule index = ((boundary * h + row) * HL + lane-in-boundary))
+    u32x4 *mail_out = nullptr;
+    const u32x4 *mail_in = nullptr;
+    {
+        u32x4 *base = L.mail + J.ws_mail;
+        const int lane_o = producer ? (x0 - (XEc - 4 * HL)) >> 2 : 0;
+        const int lane_i = lhalo ? l : 0;
+        mail_out = base + (size_t)min(strip, max(J.ws_S - 2, 0)) * h * HL + lane_o;
+        mail_in = base + (size_t)max(strip - 1, 0) * h * HL + lane_i;
+    }
+
+    // selection nibble (bit i: column x0 + i selected = mask bit set, optional inversion, inside the image) -> 0xFF bytes
+    auto nib_bytes = [&](unsigned nib) { return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u; };
+    auto nib_of_word = [&](unsigned mw) { return ((mw >> msh) ^ invn) & coln; };
+    unsigned hist[HWORDS];
+#pragma unroll
+    for (int k = 0; k < HWORDS; k++) hist[k] = 0;
+    auto hist_push = [&](unsigned nib) {
+#pragma unroll
+        for (int k = HWORDS - 1; k >= 1; k--) hist[k] = __builtin_amdgcn_alignbit(hist[k], hist[k - 1], 28);
+        hist[0] = (hist[0] << 4) | nib;
+    };
+    auto hist_at = [&](int k) -> unsigned {          // nibble pushed k pushes ago
+        const int pos = 4 * k;
+        if constexpr (NCT >= 0) return (hist[pos >> 5] >> (pos & 31)) & 0xFu;
+        else {
+            unsigned wd = hist[0];
+            if constexpr (HWORDS > 1) { if (pos >= 32) wd = hist[1]; }
+            if constexpr (HWORDS > 2) { if (pos >= 64) wd = hist[2]; }
+            return (wd >> (pos & 31)) & 0xFu;
+        }
+    };
+
+    // FIR entries of the 4 columns of a row: masked pixel bytes + selection bit
+    auto fir_entries = [&](const unsigned (&px)[ND], const unsigned on, Ent (&e)[P]) {
+        const unsigned on01 = on & 0x01010101u;
+        if constexpr (C == 3) {
+            const unsigned d0 = px[0] & __builtin_amdgcn_perm(0u, on, 0x01000000u);   // [M0 M0 M0 M1]
+            const unsigned d1 = px[1] & __builtin_amdgcn_perm(0u, on, 0x02020101u);   // [M1 M1 M2 M2]
+            const unsigned d2 = px[2] & __builtin_amdgcn_perm(0u, on, 0x03030302u);   // [M2 M3 M3 M3]
+            e[0].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(on01, d0, 0x0c040c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(on01, d1, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(d2, d1, 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c060c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(d2, d2, 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(on01, d2, 0x0c070c03u);
+        } else {
+            const unsigned d0 = px[0] & on;
+            e[0].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c040c00u);
+            e[1].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c050c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c060c02u);
+            e[3].d[0] = __builtin_amdgcn_perm(on01, d0, 0x0c070c03u);
+        }
+    };
+    // IIR entries of the 4 columns of an output row (bytes of columns outside the image must be zero)
+    auto iir_entries = [&](const unsigned (&o)[ND], Ent (&e)[P]) {
+        if constexpr (C == 3) {
+            e[0].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c010c00u); e[0].d[1] = __builtin_amdgcn_perm(0u, o[0], 0x0c0c0c02u);
+            e[1].d[0] = __builtin_amdgcn_perm(o[1], o[0], 0x0c040c03u); e[1].d[1] = __builtin_amdgcn_perm(0u, o[1], 0x0c0c0c01u);
+            e[2].d[0] = __builtin_amdgcn_perm(o[2], o[1], 0x0c030c02u); e[2].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c00u);
+            e[3].d[0] = __builtin_amdgcn_perm(o[2], o[2], 0x0c020c01u); e[3].d[1] = __builtin_amdgcn_perm(0u, o[2], 0x0c0c0c03u);
+        } else {
+            e[0].d[0] = o[0] & 0xffu; e[1].d[0] = (o[0] >> 8) & 0xffu; e[2].d[0] = (o[0] >> 16) & 0xffu; e[3].d[0] = o[0] >> 24;
+        }
+    };
+
+    Ent firE[P], iirE[P];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int k = 0; k < EW; k++) { firE[i].d[k] = 0; iirE[i].d[k] = 0; }
+    unsigned prev[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++) prev[q] = 0;
+
+    // a sparse layer (fg: the ink) mostly sees rows in which none of the wave's columns is selected: nothing to add
+    const bool sparse = !J.invert;
+    auto fir_apply = [&](const unsigned (&px)[ND], unsigned nib, bool plus) {
+        if (sparse && !__any(nib != 0u)) return;
+        Ent e[P];
+        fir_entries(px, nib_bytes(nib), e);
+#pragma unroll
+        for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
+    };
+
+    auto load_px = [&](int yy, unsigned (&px)[ND]) {
+        const int yc = min(max(yy, 0), h - 1);
+        gc_u32p pi = (gc_u32p)((img + (size_t)yc * ipitch) + vo_px);
+#pragma unroll
+        for (int q = 0; q < ND; q++) px[q] = pi[q];
+    };
+    auto load_mw = [&](int yy) {
+        const int yc = min(max(yy, 0), h - 1);
+        gc_u32p pm = (gc_u32p)((const uint8_t *)(mbits + (size_t)yc * mwpr) + vo_m);
+        return pm[0];
+    };
+    auto load_out = [&](int yy, unsigned (&o)[ND]) {
+        const int yc = min(max(yy, 0), h - 1);
+        gc_u32p p = (gc_u32p)((out + (size_t)yc * opitch) + vo_px);
+#pragma unroll
+        for (int q = 0; q < ND; q++) o[q] = p[q];
+    };
+
+    // FIR rows [0, n-1) enter before the loop (those below the image as empty rows); row y+n-1 enters at step y
+    for (int yy = 0; yy < n - 1; yy++) {
+        unsigned nib = 0;
+        if (yy < h) {
+            unsigned px[ND];
+            load_px(yy, px);
+            nib = nib_of_word(load_mw(yy));
+            fir_apply(px, nib, true);
+        }
+        hist_push(nib);
+    }
+
+    // The left halo gets the neighbour's output row y-1 as a granule and needs it again n rows later as the row that
+    // leaves the IIR sums: it keeps its last n + 1 granules in a small LDS ring (HL lanes x ND dwords per row)
+    unsigned *hring = iirA + (size_t)nelem * EW;
+    int hslot = 0;                                   // slot of row y-1 (uniform)
+
+    auto store_row = [&](int yy, const unsigned (&res)[ND]) {
+        if (!act) return;
+        uint8_t *o = out + (size_t)yy * opitch + (size_t)x0 * C;
+        if (x0 + P <= XE) {
+#pragma unroll
+            for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+        } else {
+            const int nbytes = (XE - x0) * C;
+#pragma unroll
+            for (int j = 0; j < P * C; j++)
+                if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
+        }
+    };
+    // (y - ys) * (x - xs) as a float per column: only changes while the window still grows (rows 0..n)
+    float kf[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) kf[i] = 0.0f;
+
+    // ONE set of input registers: a row's inputs are requested as soon as the previous row has used the registers they
+    // land in, and waited for where they are used --
+    //   mw / e / lv / ol (entering mask word, entering and leaving image row, leaving output row): used by the vertical
+    //       update at the top of a row, re-requested right behind it (3/4 of a row ahead);
+    //   the current image row: requested into the registers of `prev` once the previous output row has been stored,
+    //       handed on and added to the IIR sums; used by the merge at the bottom of the row, which leaves the new output
+    //       row in those very registers;
+    //   the neighbour's granule: requested behind the vertical update, used at the top of the next row.
+    unsigned mw, e_px[ND], lv_px[ND], ol[ND];
+    u32x4 mbp = {0, 0, 0, 0};
+    mw = load_mw(n - 1);
+    load_px(n - 1, e_px);
+    load_px(0, lv_px);
+#pragma unroll
+    for (int q = 0; q < ND; q++) ol[q] = 0;
+
+    for (int y = 0; y < h; y++) {
+        // ---- the previous output row leaves: store, hand-off, IIR ----
+        if (y >= 1) {
+            store_row(y - 1, prev);
+            const unsigned tag_prev = L.tagbase + (unsigned)(y - 1);
+            if (producer)
+                ws_mail_store(mail_out + (size_t)(y - 1) * HL, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
+            if (strip > 0) {
+                // the neighbour's output row y-1 (asked for during the previous row): poll until it is this launch's
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
+                int spins = 0;
+                while (__any(lhalo && mbp.w != tag_prev)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)(y - 1) * HL) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
+                    if (++spins > (1 << 22)) { if (l == 0) __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                }
+                hslot = hslot == n ? 0 : hslot + 1;
+                if (lhalo) {
+                    prev[0] = mbp.x; if constexpr (ND > 1) prev[1] = mbp.y; if constexpr (ND > 2) prev[2] = mbp.z;
+                    // row y-n-1 comes back out of the ring (the slot after the one row y-1 goes into), row y-1 goes in
+                    const int sr = hslot == n ? 0 : hslot + 1;
+                    unsigned *pr = hring + (sr * HL + l) * ND, *pw = hring + (hslot * HL + l) * ND;
+#pragma unroll
+                    for (int q = 0; q < ND; q++) { ol[q] = pr[q]; }
+#pragma unroll
+                    for (int q = 0; q < ND; q++) { pw[q] = prev[q]; }
+                }
+            }
+            if (n >= 1) {
+                Ent e[P];
+                iir_entries(prev, e);
+#pragma unroll
+                for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+            }
+        }
+        // ---- the current image row is requested into the registers of `prev` ----
+        asm volatile("" : "+v"(vo_m), "+v"(vo_px));          // keeps `row base + lane offset` addressing (k_optimise.hip)
+        load_px(y, prev);
+
+        // ---- mask: the entering row's nibble goes in, the current and the leaving row's come out ----
+        const unsigned nib_e = (y + n - 1 < h) ? nib_of_word(mw) : 0u;
+        hist_push(nib_e);
+        const unsigned nib_c = hist_at(n - 1), nib_l = hist_at(2 * n);
+
+        // ---- vertical running sums for row y (wave-uniform row tests) ----
+        if (y + n - 1 < h && n >= 1) fir_apply(e_px, nib_e, true);        // ye = min(h, y+n)
+        if (y - n - 1 >= 0 && n >= 1) {
+            fir_apply(lv_px, nib_l, false);                                // ys = max(0, y-n)
+            unsigned o[ND];
+#pragma unroll
+            for (int q = 0; q < ND; q++) o[q] = ol[q] & pxm[q];
+            Ent e[P];
+            iir_entries(o, e);
+#pragma unroll
+            for (int i = 0; i < P; i++) esub(iirE[i], e[i]);
+        }
+        // ---- their registers are free: the next row's inputs ----
+        {
+            const int yn = y + 1;
+            mw = load_mw(yn + n - 1);
+            load_px(yn + n - 1, e_px);
+            load_px(yn - n - 1, lv_px);
+            load_out(yn - n - 1, ol);
+            if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)min(y, h - 1) * HL) : "memory");
+        }
+        if (y <= n) {
+            asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
+#pragma unroll
+            for (int i = 0; i < P; i++) kf[i] = (float)(y * min(max(x0 + i, 0), n));          // (y - ys) * (x - xs) while y <= n
+        }
+
+        // ---- publish: the registers already hold the LDS entry format ----
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int e = eidx(i);
+            Ent second = iirE[i];
+            if constexpr (SUMROW) eadd(second, firE[i]);
+            if constexpr (EW == 2) {
+                *reinterpret_cast<uint2 *>(firA + e) = make_uint2(firE[i].d[0], firE[i].d[1]);
+                *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(second.d[0], second.d[1]);
+            } else {
+                firA[e] = firE[i].d[0];
+                iirA[e] = second.d[0];
+            }
+        }
+        asm volatile("" ::: "memory");            // one wave: its LDS operations execute in order, no barrier, no wait
+
+        // Only pixels with mask==0 get a quotient; a wave-row in which every core pixel is selected is a copy
+        const unsigned on_cur = nib_bytes(nib_c);
+        unsigned qd[ND];
+#pragma unroll
+        for (int q = 0; q < ND; q++) qd[q] = 0;
+        if (__any(act && on_cur != colm)) {
+        Ent aL, aR, aI;
+#pragma unroll
+        for (int k = 0; k < EW; k++) { aL.d[k] = 0; aR.d[k] = 0; aI.d[k] = 0; }
+        if constexpr (SUMROW) {
+#pragma unroll
+            for (int j = -NCT; j < 0; j++) eadd(aL, lds_ld(iirA, j));          // (fir + iir)[x0 + j]
+#pragma unroll
+            for (int j = 0; j < NCT; j++) eadd(aL, j < P ? firE[j < P ? j : 0] : lds_ld(firA, j));
+        } else if constexpr (NCT >= 0) {
+#pragma unroll
+            for (int j = -NCT; j < 0; j++) { eadd(aL, lds_ld(firA, j)); eadd(aI, lds_ld(iirA, j)); }
+#pragma unroll
+            for (int j = 0; j < NCT; j++) {
+                const Ent e = j < P ? firE[j < P ? j : 0] : lds_ld(firA, j);
+                if constexpr (NH == 2) eadd(aR, e); else eadd(aL, e);
+            }
+        } else {
+            for (int j = -n; j < 0; j++) { eadd(aL, lds_ld(firA, j)); eadd(aI, lds_ld(iirA, j)); }
+            for (int j = 0; j < n; j++) eadd(aR, lds_ld(firA, j));
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            float fsum[C], fcnt;
+            if constexpr (SUMROW) {
+                const Ent T = aL;
+                if constexpr (C == 3) {
+                    fsum[0] = (float)(T.d[0] & 0xffffu); fsum[1] = (float)(T.d[0] >> 16);
+                    fsum[2] = (float)(T.d[1] & 0xffffu); fcnt = (float)(T.d[1] >> 16);
+                } else {
+                    fsum[0] = (float)(T.d[0] & 0xffffu); fcnt = (float)(T.d[0] >> 16);
+                }
+            } else if constexpr (C == 3 && NH == 2) {
+                fsum[0] = (float)ws_add_dw0(ws_add_w0w0(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[1] = (float)ws_add_dw1(ws_add_w1w1(aL.d[0], aR.d[0]), aI.d[0]);
+                fsum[2] = (float)ws_add_dw0(ws_add_w0w0(aL.d[1], aR.d[1]), aI.d[1]);
+                fcnt = (float)ws_add_w1w1(aL.d[1], aR.d[1]);
+            } else if constexpr (C == 3) {
+                fsum[0] = (float)((aL.d[0] & 0xffffu) + (aI.d[0] & 0xffffu));
+                fsum[1] = (float)((aL.d[0] >> 16) + (aI.d[0] >> 16));
+                fsum[2] = (float)((aL.d[1] & 0xffffu) + (aI.d[1] & 0xffffu));
+                fcnt = (float)(aL.d[1] >> 16);
+            } else {
+                unsigned f0 = (aL.d[0] & 0xffffu) + aI.d[0], c0 = aL.d[0] >> 16;
+                if constexpr (NH == 2) { f0 += aR.d[0] & 0xffffu; c0 += aR.d[0] >> 16; }
+                fsum[0] = (float)f0; fcnt = (float)c0;
+            }
+            // floor(v / cnt) = round-to-nearest-even((v + 0.5) / cnt - 0.5) -- exhaustive self-test in k_optimise.hip
+            const float rc = __builtin_amdgcn_rcpf(__builtin_fmaxf(fcnt + kf[i], 1.0f));
+            const float qoff = __builtin_fmaf(rc, 0.5f, -0.5f);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int jb = i * C + c;
+                qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rc, qoff), jb & 3, qd[jb >> 2]);
+            }
+            if (i + 1 < P) {      // slide to pixel x+1 (own columns' entries come from registers)
+                if constexpr (SUMROW) {
+                    eadd(aL, (i + NCT < P) ? firE[(i + NCT < P) ? i + NCT : 0] : lds_ld(firA, i + NCT));
+                    eadd(aL, iirE[i]);
+                    esub(aL, lds_ld(iirA, i - NCT));
+                } else {
+                    if constexpr (NH == 2) {
+                        eadd(aL, firE[i]); esub(aL, lds_ld(firA, i - n));
+                        eadd(aR, lds_ld(firA, i + n)); esub(aR, firE[i]);
+                    } else {
+                        eadd(aL, lds_ld(firA, i + n)); esub(aL, lds_ld(firA, i - n));
+                    }
+                    eadd(aI, iirE[i]); esub(aI, lds_ld(iirA, i - n));
+                }
+            }
+        }
+        }
+        // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient: `prev` holds the
+        // current image row (requested at the top of this row) and becomes the output row
+        {
+            const unsigned on = on_cur;
+            if constexpr (C == 3) {
+                const unsigned e0 = __builtin_amdgcn_perm(0u, on, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on, 0x02020101u),
+                               e2 = __builtin_amdgcn_perm(0u, on, 0x03030302u);
+                prev[0] = ((prev[0] & e0) | (qd[0] & ~e0)) & pxm[0];
+                prev[1] = ((prev[1] & e1) | (qd[1] & ~e1)) & pxm[1];
+                prev[2] = ((prev[2] & e2) | (qd[2] & ~e2)) & pxm[2];
+            } else {
+                prev[0] = ((prev[0] & on) | (qd[0] & ~on)) & pxm[0];
+            }
+        }
+    }
+    if (h >= 1) store_row(h - 1, prev);
+}
+
+#ifndef MRCHIP_WS_WAVES
+#define MRCHIP_WS_WAVES 4
+#endif
+
+// grid = jobs * smax single-wave workgroups: job = block / smax, strip = block % smax (left strips first)
+template <int C, int GENERIC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MRCHIP_WS_WAVES, 8)))
+void optimise_ws_kernel(const OptJob *jobs, WsLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int job = blockIdx.x / L.smax, strip = blockIdx.x - job * L.smax;
+    const OptJob J = jobs[job];
+    if (strip >= J.ws_S) return;
+    unsigned *lds = reinterpret_cast<unsigned *>(smem);
+    if constexpr (GENERIC) ws_rows<C, -1>(J, lds, L, strip);
+    else {
+        if (J.n == 3) ws_rows<C, 3>(J, lds, L, strip);              // fg, mrc.py:413/415
+        else ws_rows<C, 10>(J, lds, L, strip);                      // bg, mrc.py:447/449
+    }
+}
+
+// strips of a job: HL + HR halo lanes, the core lanes shared out evenly
+void ws_geometry(int w, int n, int *S, int *clb) {
+    const int HL = (n + 3) >> 2, HR = (n + 2) >> 2;
+    const int CL = 64 - HL - HR;
+    const int w4 = cdiv(w, 4);
+    *S = std::max(1, cdiv(w4, CL));
+    *clb = cdiv(w4, *S);
+}
+
+bool ws_supported(int w, int h, int n_max, int n_min) {
+    static const bool off = getenv("MRCHIP_OPT_WS") && atoi(getenv("MRCHIP_OPT_WS")) == 0;
+    return !off && n_min >= 1 && n_max <= 11 && h < 65536 && w >= 1;
+}
+
+// h_jobs: host copy (its ws_* fields are filled here), d_jobs: where it is uploaded to.  All jobs share w, h, c; every
+// job has mbits.  Returns 0 / error.
+int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
+                       OptMail *mail, double alg) {
+    int smax = 1;
+    bool generic = false;
+    size_t granules = 16;                                   // first 256 bytes: the error word
+    for (int i = 0; i < njobs; i++) {
+        OptJob &j = h_jobs[i];
+        ws_geometry(w, j.n, &j.ws_S, &j.ws_clb);
+        j.ws_mail = granules;
+        granules += (size_t)std::max(j.ws_S - 1, 0) * h * ((j.n + 3) >> 2);
+        smax = std::max(smax, j.ws_S);
+        if (j.n != 3 && j.n != 10) generic = true;
+    }
+    const size_t need = granules * sizeof(u32x4);
+    if (need > mail->bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        TRY(mail->buf.alloc(ctx, need + need / 8));
+        mail->bytes = need + need / 8;
+        mail->epoch = 0;
+    }
+    if (mail->epoch == 0 || mail->epoch >= 0xfffe) {       // fresh buffer, or the 16-bit epoch is about to repeat
+        HIP_TRY(hipMemsetAsync(mail->buf.p, 0, mail->bytes, s));
+        mail->epoch = 0;
+    }
+    mail->epoch++;
+    HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
+    WsLaunch L;
+    L.mail = mail->buf.as<u32x4>();
+    L.tagbase = mail->epoch << 16;
+    L.err = mail->err;
+    L.smax = smax;
+    int n_max = 0;
+    for (int i = 0; i < njobs; i++) n_max = std::max(n_max, h_jobs[i].n);
+    const int nent = 64 * 4 + 2 * n_max;
+    // two rows of column-sum entries + the left halo's ring of n + 1 granules
+    const size_t lds = 2 * (size_t)(nent + nent / 4 + 1) * ((c == 3) ? 8 : 4) + (size_t)(n_max + 1) * ((n_max + 3) / 4) * c * 4;
+    const char *nm = c == 3 ? "optimise_rgb" : "optimise_gray";
+    const long long blocks = (long long)njobs * smax;
+    if (blocks > 0x7fffffffLL) { set_error("optimise: %lld strips in one launch", blocks); return MRCHIP_E_UNSUPPORTED; }
+#define WS_LAUNCH(CC, GG)                                                                                        \
+    LAUNCH(ctx, s, nm, alg, hipLaunchKernelGGL((optimise_ws_kernel<CC, GG>), dim3((unsigned)blocks), dim3(64), lds, s, d_jobs, L))
+    if (c == 3) { if (generic) WS_LAUNCH(3, 1); else WS_LAUNCH(3, 0); }
+    else { if (generic) WS_LAUNCH(1, 1); else WS_LAUNCH(1, 0); }
+#undef WS_LAUNCH
+    return 0;
+}
+
+}  // namespace mrchip

@@ -217,12 +217,38 @@ struct OptJob {
     // optional: the same mask at 1 bit per pixel (LSB first, mwpr dwords per row) as the denoiser leaves it;
     // the packed kernel reads it instead of the byte mask (an eighth of the traffic of 3 reads per row)
     const unsigned *mbits; int mwpr;
+    // wave-strip schedule (k_optimise_ws.hip), filled by the launcher: strips of this job, core lanes per strip, first
+    // granule of the job's part of the hand-off buffer
+    int ws_S, ws_clb;
+    size_t ws_mail;
 };
-// hand-off buffer of the column-strip schedule (one per owner that may have a launch in flight: a batch, or a host-buffer
-// call); nullptr = whole rows only
-struct OptMail { DevBuf buf; size_t bytes = 0; unsigned epoch = 0; };
-int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, const OptJob *d_jobs, int njobs, int w, int h, int c, int n_max,
-                         OptMail *mail = nullptr);
+// hand-off buffer of the strip schedules (one per owner that may have a launch in flight: a batch, or a host-buffer
+// call).  The first 256 bytes of `buf` are unused padding; `err` is a page-locked host word the kernels set when a
+// bounded poll gives up (the owner reads it after it has synchronised with the stream: optmail_check).
+struct OptMail {
+    DevBuf buf;
+    size_t bytes = 0;
+    unsigned epoch = 0;
+    unsigned *err = nullptr;
+    DevBuf bits;              // 1-bpp copy of a byte mask for callers that have none (host-buffer entry point)
+    size_t bits_bytes = 0;
+    OptMail() = default;
+    OptMail(const OptMail &) = delete;
+    OptMail &operator=(const OptMail &) = delete;
+    ~OptMail();
+};
+// MRCHIP_E_HIP (and the word cleared) if a launch since the last check reported a hand-off timeout; call with the
+// stream idle
+int optmail_check(OptMail *mail);
+// h_jobs: host copy of the job records (the launcher fills the schedule's fields and uploads them to d_jobs on `s`;
+// it must stay valid until the copy has run)
+int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
+                         int n_max, OptMail *mail);
+bool ws_supported(int w, int h, int n_max, int n_min);
+int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
+                       OptMail *mail, double alg);
+// bytes != 0 -> 1 bit per pixel, LSB first, wpr dwords per row (the denoiser's rows)
+int launch_pack_bits(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int pitch, int w, int h, unsigned *bits, int wpr);
 
 
 // hOCR: commit chosen thresholds into the mask in list order

@@ -457,6 +457,7 @@ class _StreamSlot:
         self.batch = Batch(ctx, n, w, h, c)
         self.ctx = ctx
         self.key = (n, w, h, c)
+        self.stamp = 0              # StreamPool's clock at the last take / give
         self.out = {}               # name -> pinned array [n, ...]
 
     def pinned(self, name, shape):
@@ -471,26 +472,69 @@ class _StreamSlot:
         self.out.clear()
 
 
+def _slot_bytes(n, w, h, c):
+    """Device bytes a _StreamSlot of n pages holds, roughly (planes of a batch) -- the page-locked result
+    arrays on the host side are about a third of it."""
+    return int(n) * (int(w) * int(h) * (10 + 6 * int(c)) + (4 << 20))
+
+
 class StreamPool:
     """The device batches and page-locked result arrays of decompose_stream, kept between calls: creating them
     (tens of GB of hipMalloc / hipHostMalloc for 4000x3000 pages) costs more than decomposing a few hundred pages,
-    so a long-running caller makes one pool and passes it to every decompose_stream(..., pool=pool)."""
+    so a long-running caller makes one pool and passes it to every decompose_stream(..., pool=pool).
 
-    def __init__(self, ctx=None):
+    A slot serves batches of its geometry (w, h, c) with up to its `n` pages.  Books whose pages all differ in size
+    would otherwise leave one idle slot per size behind: the pool keeps at most `max_bytes` of device memory
+    (default: a quarter of the device) and closes idle slots of OTHER geometries, least recently used first, before
+    it makes a new one; slots are sized to the run of pages they are made for, not to `batch_pages`."""
+
+    def __init__(self, ctx=None, max_bytes=None):
         self.ctx = ctx or _lib.default_context()
-        self.free = {}             # (n, w, h, c) -> [idle _StreamSlot]
+        self.free = {}             # (w, h, c) -> [idle _StreamSlot], most recently used last
         self.every = []
+        self.clock = 0
+        if max_bytes is None:
+            try:
+                max_bytes = self.ctx.info()['hbm_bytes'] // 4
+            except Exception:       # noqa: BLE001 - no device query: a fixed, modest cap
+                max_bytes = 32 << 30
+        self.max_bytes = int(max_bytes)
 
-    def take(self, n, w, h, c):
-        idle = self.free.setdefault((n, w, h, c), [])
-        if idle:
-            return idle.pop()
-        sl = _StreamSlot(self.ctx, n, w, h, c)
-        self.every.append(sl)
+    def bytes_held(self):
+        return sum(_slot_bytes(*sl.key) for sl in self.every)
+
+    def _evict(self, need, keep_geo):
+        """close idle slots (never one of geometry keep_geo unless nothing else is left) until `need` more bytes fit"""
+        idle = sorted((sl for lst in self.free.values() for sl in lst), key=lambda sl: (sl.key[1:] == keep_geo, sl.stamp))
+        for sl in idle:
+            if self.bytes_held() + need <= self.max_bytes:
+                break
+            self.free[sl.key[1:]].remove(sl)
+            self.every.remove(sl)
+            sl.close()              # idle = drained: nothing of it is pending on its stream
+
+    def take(self, n, w, h, c, capacity=None):
+        """a slot for a batch of n pages of w x h x c: an idle one of that geometry with room for n, else a new one of
+        `capacity` (>= n, default n) pages"""
+        geo = (w, h, c)
+        self.clock += 1
+        idle = self.free.setdefault(geo, [])
+        fit = [sl for sl in idle if sl.key[0] >= n]
+        if fit:
+            sl = min(fit, key=lambda sl: sl.key[0])
+            idle.remove(sl)
+        else:
+            cap = max(n, capacity or n)
+            self._evict(_slot_bytes(cap, w, h, c), geo)
+            sl = _StreamSlot(self.ctx, cap, w, h, c)
+            self.every.append(sl)
+        sl.stamp = self.clock
         return sl
 
     def give(self, slot):
-        self.free[slot.key].append(slot)
+        self.clock += 1
+        slot.stamp = self.clock
+        self.free.setdefault(slot.key[1:], []).append(slot)
 
     def close(self):
         for sl in self.every:
@@ -547,7 +591,9 @@ def decompose_stream(pages, dpi=None, downsample=None, bg_downsample=None, fg_do
     def fill(items):
         h, w = items[0][0].shape[:2]
         c = 1 if items[0][0].ndim == 2 else 3
-        job = _StreamJob(take_slot(batch_pages, w, h, c), items)
+        # a full run gets (or makes) a slot of batch_pages pages; a short one -- a page size that occurs once or twice
+        # in a row -- only what it needs, so a book of many sizes does not hold batch_pages pages per size
+        job = _StreamJob(take_slot(len(items), w, h, c, capacity=batch_pages if len(items) == batch_pages else None), items)
         bt = job.slot.batch
         t0 = time()
         for j, (arr, gray, hocr) in enumerate(items):

@@ -178,6 +178,48 @@ def pmc_traffic(name, alg_per_launch):
         return None, None
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process never touches the GPU, starts N fresh child processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; ordinary children, never os.exec*), relays rank 0's JSON line on its
+    own stdout and everything else on stderr, and exits non-zero if any rank does."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MRCHIP_BENCH_SPAWNED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    import threading
+    outs = [''] * n
+
+    def drain(r):                       # all pipes are read at once: no rank ever blocks on a full one
+        outs[r] = procs[r].communicate()[0]
+
+    ths = [threading.Thread(target=drain, args=(r,)) for r in range(n)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith('{')]
+    for r, out in enumerate(outs):
+        for ln in out.splitlines():
+            if not (r == 0 and lines and ln == lines[-1]):
+                sys.stderr.write('[rank %d] %s\n' % (r, ln))
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %r\n' % (bad,))
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    elif not bad:
+        sys.stderr.write('bench.py: rank 0 printed no result line\n')
+        return 1
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -198,9 +240,29 @@ def main():
     W, H, Cc = cfg['w'], cfg['h'], cfg['c']
     sauvola_only = a.config == 'c3gray'
 
+    if a.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))        # no launcher: be the launcher
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (a.gpus, world))
+        sys.exit(2)
+    if os.environ.get('MRCHIP_BENCH_DRYRUN'):
+        # CPU test hook of the rank plumbing (no GPU, no library): the ranks meet over gloo, rank 0 prints a line
+        import torch.distributed as tdist
+        from mrchip import dist as mdist
+        tdist.init_process_group('gloo')
+        comm = mdist.TorchComm(tdist)
+        ids = comm.allgather_obj({'rank': rank, 'local_rank': local_rank, 'pages': mdist.shard_pages(8, rank, world)})
+        if os.environ.get('MRCHIP_BENCH_DRYRUN') == 'fail' and rank == world - 1:
+            sys.exit(7)
+        if rank == 0:
+            print(json.dumps({'dryrun': True, 'n_gpus': world, 'ranks': ids, 'spawned': bool(os.environ.get('MRCHIP_BENCH_SPAWNED'))}))
+        comm.barrier()
+        return
 
     # the CPU baseline forks worker processes: before the first GPU call of this process
     cpu = None
@@ -215,6 +277,9 @@ def main():
     transport = 'none (one rank)'
     if world == 1:
         comm = mdist.SoloComm()
+        if not a.no_extras and os.environ.get('MRCHIP_BENCH_RCCL1', '1') != '0':
+            # the same control-plane code the N > 1 runs use, on a communicator of one: says whether RCCL works on this box
+            comm, transport = rccl_of_one(ctx, mdist)
     elif os.environ.get('MRCHIP_BENCH_COMM') == 'gloo':
         # test hook: the N > 1 logic of this file on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
         # GPU); the ranks then share GPU local_rank mod visible-devices
@@ -347,6 +412,15 @@ def main():
     for bt in batches:
         bt.close()
     batches = []
+    # how many ranks the control plane really joined (an allgather of one byte per rank over it), and whether it is RCCL
+    rccl_ok = transport.startswith('rccl')
+    joined = len(comm.allgather_bytes(b'r'))
+    if rank == 0:
+        extra['rccl_ok'] = bool(rccl_ok)
+        extra['rccl_ranks'] = joined if rccl_ok else 0
+        extra['control_plane_ranks'] = joined
+        if world > 1 and not rccl_ok:
+            sys.stderr.write('bench.py: WARNING: %d ranks, control plane is NOT RCCL: %s\n' % (world, transport))
 
     if not a.no_extras and not sauvola_only and a.e2e_pages > 0:
         e2e = e2e_stream(ctx, comm, mrc, cfg, host_pages, a.e2e_pages, rank, world)
@@ -443,6 +517,30 @@ def main():
         print(json.dumps(line))
     comm.barrier()
     comm.close()
+
+
+def rccl_of_one(ctx, mdist):
+    """(comm, description) for a single rank: an RCCL communicator of one when librccl can make it (the calls of a
+    multi-GPU run, exercised on every default run), else SoloComm -- said so in the line, never fatal."""
+    import threading
+    box = {}
+
+    def init():
+        try:
+            box['comm'] = mdist.RcclComm(ctx, 0, 1, rendezvous=mdist.rendezvous_path() + '_solo%d' % os.getpid(),
+                                         redirect_stdout=False)
+        except Exception as e:          # noqa: BLE001
+            box['err'] = '%s: %s' % (type(e).__name__, e)
+
+    th = threading.Thread(target=init, daemon=True)
+    with mdist._stdout_to_stderr(True):
+        th.start()
+        th.join(60.0)
+    if 'comm' in box:
+        return box['comm'], 'rccl (communicator of one rank)'
+    why = box.get('err', 'ncclCommInitRank did not return within 60 s')
+    sys.stderr.write('bench.py: RCCL communicator of one rank unavailable: %s\n' % why)
+    return mdist.SoloComm(), 'none (one rank; RCCL unavailable -- %s)' % why
 
 
 def _layer_size(w, h, ds):
