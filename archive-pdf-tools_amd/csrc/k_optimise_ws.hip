@@ -303,20 +303,31 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     for (int y = 0; y < h; y++) {
         // ---- the previous output row leaves: store, hand-off, IIR ----
         if (y >= 1) {
-            store_row(y - 1, prev);
             const unsigned tag_prev = L.tagbase + (unsigned)(y - 1);
-            if (producer)
-                ws_mail_store(mail_out + (size_t)(y - 1) * HL, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
+            // (the wait for the neighbour's granule comes BEFORE this row's stores: vmcnt retires in order, behind them
+            // it would wait for their write acknowledgements as well)
             if (strip > 0) {
                 // the neighbour's output row y-1 (asked for during the previous row): poll until it is this launch's
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
                 int spins = 0;
+#ifdef MRCHIP_WS_EXP
+                if (false)
+#endif
                 while (__any(lhalo && mbp.w != tag_prev)) {
                     __builtin_amdgcn_s_sleep(2);
                     if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)(y - 1) * HL) : "memory");
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
                     if (++spins > (1 << 22)) { if (l == 0) __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 }
+            }
+            store_row(y - 1, prev);
+#if defined(MRCHIP_WS_EXP) && MRCHIP_WS_EXP == 1
+            if (false)
+#else
+            if (producer)
+#endif
+                ws_mail_store(mail_out + (size_t)(y - 1) * HL, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
+            if (strip > 0) {
                 hslot = hslot == n ? 0 : hslot + 1;
                 if (lhalo) {
                     prev[0] = mbp.x; if constexpr (ND > 1) prev[1] = mbp.y; if constexpr (ND > 2) prev[2] = mbp.z;

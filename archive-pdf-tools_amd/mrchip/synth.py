@@ -165,6 +165,25 @@ def kat_pattern(w, h, channels=1):
     return np.ascontiguousarray(px[:, :, 0] if channels == 1 else px)
 
 
+def pil_mode_image(rgb, mode):
+    """A PIL image of `mode` made from an RGB array, the way tests/golden/make_golden.py made the mode vectors.
+    Mode 'P' is built from an explicit 3-3-2 palette (index = RRRGGGBB of the pixel, Image.putpalette) instead of
+    `convert('P')`, whose adaptive quantiser differs between Pillow versions: every other mode goes through
+    Pillow's fixed-formula conversions."""
+    from PIL import Image
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    if mode != 'P':
+        return Image.fromarray(rgb).convert(mode)
+    idx = (rgb[..., 0] & 0xE0) | ((rgb[..., 1] & 0xE0) >> 3) | (rgb[..., 2] >> 6)
+    pal = []
+    for i in range(256):
+        r, g, b = (i >> 5) & 7, (i >> 2) & 7, i & 3
+        pal += [(r * 255) // 7, (g * 255) // 7, (b * 255) // 3]
+    im = Image.fromarray(idx.astype(np.uint8), 'P')
+    im.putpalette(pal)
+    return im
+
+
 def synth_pages(specs, threads=None):
     """[synth_page(**spec) for spec in specs] on a thread pool (numpy releases the GIL in the array work);
     spec = dict of synth_page's arguments."""

@@ -322,8 +322,12 @@ def create_mrc_hocr_components(image, hocr_word_data, dpi=None, downsample=None,
 
     `image` is a uint8 ndarray [H,W] ('L') or [H,W,3] ('RGB') (or a PIL image).
     """
+    gray_of_original = None
     if hasattr(image, 'mode'):
         if image.mode not in ('L', 'RGB'):
+            # mrc.py:359-361 thresholds image.convert('L') of the ORIGINAL image (Pillow's own rule for that mode, not the
+            # luma of the RGB conversion); mrc.py:401-404 converts to RGB for the layers only
+            gray_of_original = _u8(np.array(image.convert('L')))
             image = image.convert('RGB')
         image = np.array(image)
     img = _u8(image)
@@ -333,7 +337,7 @@ def create_mrc_hocr_components(image, hocr_word_data, dpi=None, downsample=None,
         if denoise_mask == 'bregman':
             raise NotImplementedError('bregman denoise is out of scope (SURVEY.md 2 #11)')
         raise ValueError('Invalid denoise option:', denoise_mask)
-    gray = luma601(img) if c == 3 else img
+    gray = gray_of_original if gray_of_original is not None else (luma601(img) if c == 3 else img)
     mask = np.zeros((h, w), dtype=np.bool_)
     boxes = hocr_boxes(hocr_word_data, w, h, downsample)
     dec = []

@@ -66,26 +66,44 @@ def test_threshold_image_reference_vectors():
     assert sha(t) == d['out'] and int(t.sum()) == d['sum']
 
 
-def test_pil_modes_other_than_l_and_rgb():
+MODE_CASES = ['YCbCr', 'CMYK', 'P', 'RGBA', 'LA', '1', 'HSV']          # order of tests/golden/make_golden.py
+
+
+@pytest.mark.parametrize('mode', MODE_CASES)
+def test_pil_modes_other_than_l_and_rgb(mode):
     """mrc.py:359-361 thresholds image.convert('L') of the ORIGINAL image; mrc.py:401-404 converts to RGB for the
-    layers only.  Reference-made pages in YCbCr, CMYK, P, RGBA, LA, 1, HSV."""
-    Image = pytest.importorskip('PIL.Image')
+    layers only.  Reference-made pages, one case per mode (a Pillow that converts ONE mode differently from the one
+    that made the vectors skips that mode only; 'P' is built from an explicit palette, so no quantiser is involved)."""
+    pytest.importorskip('PIL.Image')
     z, md, _ = _modes()
-    for i, m in enumerate(md):
-        rgb, hocr = synth.synth_page(360, 280, 3, seed=m['seed'], noise_sigma=5.0, line_div=14)
-        im = Image.fromarray(rgb).convert(m['mode'])
-        if sha(np.array(im.convert('L'))) != m['gray_sha'] or sha(np.array(im.convert('RGB'))) != m['rgb_sha']:
-            pytest.skip('this Pillow converts mode %s differently from the one that made the vectors' % m['mode'])
-        td = []
-        g = mrc.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast', timing_data=td)
-        mask, fg, bg = next(g), next(g), next(g)
+    i = MODE_CASES.index(mode)
+    m = md[i]
+    assert m['mode'] == mode
+    rgb, hocr = synth.synth_page(360, 280, 3, seed=m['seed'], noise_sigma=5.0, line_div=14)
+    im = synth.pil_mode_image(rgb, mode)
+    assert im.mode == mode
+    same_pillow = sha(np.array(im.convert('L'))) == m['gray_sha'] and sha(np.array(im.convert('RGB'))) == m['rgb_sha']
+    td = []
+    g = mrc.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast', timing_data=td)
+    mask, fg, bg = next(g), next(g), next(g)
+    assert [k for k, _ in td] == m['keys']
+    # the oracle takes the two planes this Pillow makes (convert('L') of the original for the mask, convert('RGB') for
+    # the layers): the conversion itself is Pillow's on both sides, as it is in the reference
+    o = O.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast')
+    om, ofg, obg = next(o), next(o), next(o)
+    assert np.array_equal(mask, om) and np.array_equal(fg, ofg) and np.array_equal(bg, obg), mode
+    exp = om
+    if same_pillow:                  # and against what the reference itself yielded (with the Pillow of the vectors)
         exp = unpack(z['md_mask_%d' % i], 360)
-        assert np.array_equal(mask, exp), (m['mode'], int((mask != exp).sum()))
-        assert np.array_equal(fg, z['md_fg_%d' % i]) and np.array_equal(bg, z['md_bg_%d' % i]), m['mode']
-        assert [k for k, _ in td] == m['keys']
-        # the batch form takes the same two planes
-        (bm, bf, bb), = mrc.decompose_pages([im], [hocr], bg_downsample=2)
-        assert np.array_equal(bm, exp) and np.array_equal(bf, fg) and np.array_equal(bb, bg)
+        assert np.array_equal(mask, exp), (mode, int((mask != exp).sum()))
+        assert np.array_equal(fg, z['md_fg_%d' % i]) and np.array_equal(bg, z['md_bg_%d' % i]), mode
+    else:
+        # Pillow changed its P -> L rounding between 8.4 (the vectors) and 12 (this box): the reference vector of this
+        # mode does not apply here; the oracle comparison above stands
+        assert mode == 'P', 'Pillow converts mode %s differently from the one that made the vectors' % mode
+    # the batch form takes the same two planes
+    (bm, bf, bb), = mrc.decompose_pages([im], [hocr], bg_downsample=2)
+    assert np.array_equal(bm, exp) and np.array_equal(bf, fg) and np.array_equal(bb, bg)
 
 
 def test_bregman_is_a_host_passthrough():

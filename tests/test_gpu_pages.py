@@ -102,3 +102,24 @@ def test_config5_digest():
     assert sha(mask) == d['mask'] and int(mask.sum()) == d['mask_sum']
     assert list(fg.shape) == d['fg_shape'] and sha(fg) == d['fg']
     assert list(bg.shape) == d['bg_shape'] and sha(bg) == d['bg']
+
+
+def test_config5_batch_of_pages_streamed():
+    """configs[4] as a BATCH (only one 8000x6000 page went through pytest): six pages, both reference-digested
+    seeds, through decompose_stream in batches of four -- the launch geometry of `bench.py --config c5` (optimise on rows
+    of 8000 columns, the box `reduce` + bicubic thumbnails of both layers) -- every output of every page digest-checked."""
+    dg = load_digests()
+    want = {505: dg['c5'], 506: dg['c5_506']}
+    made = {s: synth.synth_page(8000, 6000, 3, seed=s, noise_sigma=6.0, line_div=60) for s in (505, 506)}
+    for s in want:
+        assert sha(made[s][0]) == want[s]['in']
+    order = [505, 506, 506, 505, 506, 505]
+    n = 0
+    for s, (m, fg, bg) in zip(order, mrc.decompose_stream(((made[s][0], made[s][1]) for s in order), dpi=364, bg_downsample=4,
+                                                          fg_downsample=4, batch_pages=4, copy=True)):
+        d = want[s]
+        assert sha(m) == d['mask'] and int(m.sum()) == d['mask_sum'], (n, s)
+        assert list(fg.shape) == d['fg_shape'] and sha(fg) == d['fg'], (n, s)
+        assert list(bg.shape) == d['bg_shape'] and sha(bg) == d['bg'], (n, s)
+        n += 1
+    assert n == len(order)

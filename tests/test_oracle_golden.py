@@ -5,7 +5,9 @@ import pytest
 
 import mrc_oracle as O
 from mrchip import synth
-from helpers import kernel_cases, thirdparty_cases, load_npz, load_digests, unpack, sha
+import os
+
+from helpers import GOLDEN, kernel_cases, thirdparty_cases, load_npz, load_digests, unpack, sha
 
 
 def test_sauvola_golden():
@@ -158,3 +160,26 @@ def test_lanczos_ingest_downsample_against_pillow_vectors():
         i, ds, flt, gap, rw, rh = str(m).split('|')
         got = O.thumbnail_ex(z['in_' + i], int(rw), int(rh), flt, None if gap == 'None' else float(gap))
         assert got.shape == z['out_' + i].shape and np.array_equal(got, z['out_' + i]), m
+
+
+def test_oracle_follows_the_reference_for_pil_modes_other_than_l_and_rgb():
+    """mrc.py:359-361: the mask comes from image.convert('L') of the ORIGINAL image, the layers from its RGB conversion
+    (mrc.py:401-404).  Reference-made vectors (tests/golden/modes.npz); a mode this Pillow converts differently from
+    the Pillow that made them (P -> L rounding changed after 8.4) is left to the GPU-vs-oracle test."""
+    import json
+    pytest.importorskip('PIL.Image')
+    from mrchip import synth
+    z = np.load(os.path.join(GOLDEN, 'modes.npz'))
+    md = json.loads(str(z['md_meta']))
+    checked = 0
+    for i, m in enumerate(md):
+        rgb, hocr = synth.synth_page(360, 280, 3, seed=m['seed'], noise_sigma=5.0, line_div=14)
+        im = synth.pil_mode_image(rgb, m['mode'])
+        if sha(np.array(im.convert('L'))) != m['gray_sha'] or sha(np.array(im.convert('RGB'))) != m['rgb_sha']:
+            continue
+        g = O.create_mrc_hocr_components(im, hocr, dpi=None, bg_downsample=2, denoise_mask='fast')
+        mask, fg, bg = next(g), next(g), next(g)
+        assert np.array_equal(mask, unpack(z['md_mask_%d' % i], 360)), m['mode']
+        assert np.array_equal(fg, z['md_fg_%d' % i]) and np.array_equal(bg, z['md_bg_%d' % i]), m['mode']
+        checked += 1
+    assert checked >= 5
