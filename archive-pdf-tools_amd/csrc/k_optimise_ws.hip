@@ -221,16 +221,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
 #pragma unroll
     for (int q = 0; q < ND; q++) prev[q] = 0;
 
-    // a sparse layer (fg: the ink) mostly sees rows in which none of the wave's columns is selected: nothing to add
-    const bool sparse = !J.invert;
-    auto fir_apply = [&](const unsigned (&px)[ND], unsigned nib, bool plus) {
-        if (sparse && !__any(nib != 0u)) return;
-        Ent e[P];
-        fir_entries(px, nib_bytes(nib), e);
-#pragma unroll
-        for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
-    };
-
     auto load_px = [&](int yy, unsigned (&px)[ND]) {
         const int yc = min(max(yy, 0), h - 1);
         gc_u32p pi = (gc_u32p)((img + (size_t)yc * ipitch) + vo_px);
@@ -249,6 +239,27 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         for (int q = 0; q < ND; q++) o[q] = p[q];
     };
 
+    // "Rare" pixels decide how much of a row has to be done: the selected ones of a sparse layer (fg: the ink), the
+    // unselected ones of a dense layer (bg: the inverted mask).  rare_rows counts the rows of the current FIR window
+    // [y-n, y+n) that hold a rare pixel in this wave's columns (halo included).  While it is zero,
+    //   * sparse layer: all FIR sums are zero, the count of every pixel is the known (y-ys)(x-xs), no pixel of the current
+    //     row is selected -- the row takes the short path (no FIR terms, reciprocals from registers, no image row);
+    //   * dense layer: every pixel of the window is selected, i.e. out = img on all of those rows: the wave goes DORMANT --
+    //     it copies rows (and keeps the hand-off going) without maintaining any sum, and when a row with a rare pixel is about
+    //     to enter the window it rebuilds the sums from the 2n image rows of the window (out = img there, so FIR and IIR sums
+    //     both come from the image) and carries on.  A strip's sums depend on nothing outside its own columns + halo, so
+    //     each wave decides this for itself.
+    const bool sparse = !J.invert;
+    auto rare_any = [&](unsigned nib) { return sparse ? __any(nib != 0u) : __any(nib != coln); };
+    int rare_rows = 0;
+    auto fir_apply = [&](const unsigned (&px)[ND], unsigned nib, bool plus) {
+        if (sparse && !__any(nib != 0u)) return;
+        Ent e[P];
+        fir_entries(px, nib_bytes(nib), e);
+#pragma unroll
+        for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
+    };
+
     // FIR rows [0, n-1) enter before the loop (those below the image as empty rows); row y+n-1 enters at step y
     for (int yy = 0; yy < n - 1; yy++) {
         unsigned nib = 0;
@@ -257,6 +268,7 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             load_px(yy, px);
             nib = nib_of_word(load_mw(yy));
             fir_apply(px, nib, true);
+            if (rare_any(nib)) rare_rows++;
         }
         hist_push(nib);
     }
@@ -279,10 +291,22 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
                 if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
         }
     };
-    // (y - ys) * (x - xs) as a float per column: only changes while the window still grows (rows 0..n)
-    float kf[P];
+    // (y - ys) * (x - xs) as a float per column, and -- for the short path of a sparse layer, where it is the whole count
+    // -- its reciprocal and the quotient's offset: they only change while the window still grows (rows 0..n)
+    float kf[P], rcK[SUMROW ? P : 1], qoffK[SUMROW ? P : 1];
 #pragma unroll
     for (int i = 0; i < P; i++) kf[i] = 0.0f;
+    auto set_kf = [&](int yy) {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            kf[i] = (float)(min(yy, n) * min(max(x0 + i, 0), n));          // (y - ys) * (x - xs)
+            if constexpr (SUMROW) {
+                rcK[i] = __builtin_amdgcn_rcpf(__builtin_fmaxf(kf[i], 1.0f));
+                qoffK[i] = __builtin_fmaf(rcK[i], 0.5f, -0.5f);
+            }
+        }
+    };
+    set_kf(0);
 
     // ONE set of input registers: a row's inputs are requested as soon as the previous row has used the registers they
     // land in, and waited for where they are used --
@@ -299,9 +323,10 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     load_px(0, lv_px);
 #pragma unroll
     for (int q = 0; q < ND; q++) ol[q] = 0;
+    bool dormant = false;
 
     for (int y = 0; y < h; y++) {
-        // ---- the previous output row leaves: store, hand-off, IIR ----
+        // ---- the previous output row leaves: store, hand-off ----
         if (y >= 1) {
             const unsigned tag_prev = L.tagbase + (unsigned)(y - 1);
             // (the wait for the neighbour's granule comes BEFORE this row's stores: vmcnt retires in order, behind them
@@ -310,9 +335,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
                 // the neighbour's output row y-1 (asked for during the previous row): poll until it is this launch's
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
                 int spins = 0;
-#ifdef MRCHIP_WS_EXP
-                if (false)
-#endif
                 while (__any(lhalo && mbp.w != tag_prev)) {
                     __builtin_amdgcn_s_sleep(2);
                     if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)(y - 1) * HL) : "memory");
@@ -321,11 +343,7 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
                 }
             }
             store_row(y - 1, prev);
-#if defined(MRCHIP_WS_EXP) && MRCHIP_WS_EXP == 1
-            if (false)
-#else
             if (producer)
-#endif
                 ws_mail_store(mail_out + (size_t)(y - 1) * HL, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
             if (strip > 0) {
                 hslot = hslot == n ? 0 : hslot + 1;
@@ -340,21 +358,82 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
                     for (int q = 0; q < ND; q++) { pw[q] = prev[q]; }
                 }
             }
-            if (n >= 1) {
-                Ent e[P];
-                iir_entries(prev, e);
-#pragma unroll
-                for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
-            }
         }
-        // ---- the current image row is requested into the registers of `prev` ----
-        asm volatile("" : "+v"(vo_m), "+v"(vo_px));          // keeps `row base + lane offset` addressing (k_optimise.hip)
-        load_px(y, prev);
-
-        // ---- mask: the entering row's nibble goes in, the current and the leaving row's come out ----
+        // ---- the entering row's selection; dense layer: may this row be a plain copy? ----
         const unsigned nib_e = (y + n - 1 < h) ? nib_of_word(mw) : 0u;
+        const bool rare_e = (y + n - 1 < h) && rare_any(nib_e);
+#ifndef MRCHIP_WS_NODORMANT
+        if (!sparse && rare_rows == 0 && !rare_e) {
+            // DORMANT row: no unselected pixel in rows [y-n, y+n) of this wave's columns -> out = img
+            dormant = true;
+            asm volatile("" : "+v"(vo_m), "+v"(vo_px));
+            load_px(y, prev);
+            mw = load_mw(y + n);
+            if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)min(y, h - 1) * HL) : "memory");
+#pragma unroll
+            for (int q = 0; q < ND; q++) prev[q] &= pxm[q];
+            continue;
+        }
+        if (dormant) {
+            // ---- WAKE UP: the state this row would have found had the sums been kept -- FIR sums of rows [y-1-n, y-1+n),
+            // IIR sums of rows [y-1-n, y-1) (out = img on all of them: no unselected pixel), the mask history, the inputs
+            // the dormant rows did not request ----
+            dormant = false;
+#pragma unroll
+            for (int i = 0; i < P; i++)
+#pragma unroll
+                for (int k = 0; k < EW; k++) { firE[i].d[k] = 0; iirE[i].d[k] = 0; }
+            int nfir = 0;
+            for (int r = max(y - 1 - n, 0); r < min(y - 1 + n, h); r++) {
+                unsigned px[ND];
+                load_px(r, px);
+#pragma unroll
+                for (int q = 0; q < ND; q++) px[q] &= pxm[q];
+                Ent e[P];
+                iir_entries(px, e);                      // = the FIR entries of an all-selected row without their count
+#pragma unroll
+                for (int i = 0; i < P; i++) eadd(firE[i], e[i]);
+                if (r < y - 1) {
+#pragma unroll
+                    for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+                }
+                nfir++;
+            }
+#pragma unroll
+            for (int i = 0; i < P; i++) firE[i].d[EW - 1] += ((coln >> i) & 1u) * (unsigned)nfir << 16;
+            // history as it stands before this row's push: position k <-> row y+n-2-k, all valid columns selected
+#pragma unroll
+            for (int k = 0; k < HWORDS; k++) hist[k] = 0;
+            for (int k = 2 * n; k >= 0; k--) { const int r = y + n - 2 - k; hist_push((r >= 0 && r < h) ? coln : 0u); }
+            load_px(y - n - 1, lv_px);
+            if (!lhalo) {
+#pragma unroll
+                for (int q = 0; q < ND; q++) ol[q] = lv_px[q];       // out = img on the leaving row (masked where it is used)
+            }
+            load_px(y + n - 1, e_px);
+            set_kf(y);
+        }
+#endif
+        // ---- the previous output row joins the IIR sums; the current image row is requested into its registers ----
+        if (y >= 1 && n >= 1) {
+            Ent e[P];
+            iir_entries(prev, e);
+#pragma unroll
+            for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+        }
+        // ---- mask: the entering row's nibble goes in, the current and the leaving row's come out ----
         hist_push(nib_e);
         const unsigned nib_c = hist_at(n - 1), nib_l = hist_at(2 * n);
+        if (rare_e) rare_rows++;
+        if (y - n - 1 >= 0 && rare_any(nib_l)) rare_rows--;
+        // sparse layer, no selected pixel in rows [y-n, y+n): the short path (needs neither FIR sums nor the image row)
+#ifdef MRCHIP_WS_NOSHORT
+        const bool shortrow = false;
+#else
+        const bool shortrow = SUMROW && sparse && rare_rows == 0;
+#endif
+        asm volatile("" : "+v"(vo_m), "+v"(vo_px));          // keeps `row base + lane offset` addressing (k_optimise.hip)
+        if (!shortrow) load_px(y, prev);
 
         // ---- vertical running sums for row y (wave-uniform row tests) ----
         if (y + n - 1 < h && n >= 1) fir_apply(e_px, nib_e, true);        // ye = min(h, y+n)
@@ -379,8 +458,46 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         }
         if (y <= n) {
             asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
+            set_kf(y);
+        }
+        unsigned qd[ND];
 #pragma unroll
-            for (int i = 0; i < P; i++) kf[i] = (float)(y * min(max(x0 + i, 0), n));          // (y - ys) * (x - xs) while y <= n
+        for (int q = 0; q < ND; q++) qd[q] = 0;
+
+        if (shortrow) {
+            if constexpr (SUMROW) {
+                // ---- short path: T(x) = sum of the IIR column sums of [x-n, x), count = (y-ys)(x-xs) ----
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    const int e = eidx(i);
+                    if constexpr (EW == 2) *reinterpret_cast<uint2 *>(iirA + e) = make_uint2(iirE[i].d[0], iirE[i].d[1]);
+                    else iirA[e] = iirE[i].d[0];
+                }
+                asm volatile("" ::: "memory");
+                Ent aL;
+#pragma unroll
+                for (int k = 0; k < EW; k++) aL.d[k] = 0;
+#pragma unroll
+                for (int j = -NCT; j < 0; j++) eadd(aL, lds_ld(iirA, j));
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    float fsum[C];
+                    if constexpr (C == 3) {
+                        fsum[0] = (float)(aL.d[0] & 0xffffu); fsum[1] = (float)(aL.d[0] >> 16); fsum[2] = (float)(aL.d[EW - 1] & 0xffffu);
+                    } else {
+                        fsum[0] = (float)(aL.d[0] & 0xffffu);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const int jb = i * C + c;
+                        qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rcK[i], qoffK[i]), jb & 3, qd[jb >> 2]);
+                    }
+                    if (i + 1 < P) { eadd(aL, iirE[i]); esub(aL, lds_ld(iirA, i - NCT)); }
+                }
+#pragma unroll
+                for (int q = 0; q < ND; q++) prev[q] = qd[q] & pxm[q];
+            }
+            continue;
         }
 
         // ---- publish: the registers already hold the LDS entry format ----
@@ -401,9 +518,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
 
         // Only pixels with mask==0 get a quotient; a wave-row in which every core pixel is selected is a copy
         const unsigned on_cur = nib_bytes(nib_c);
-        unsigned qd[ND];
-#pragma unroll
-        for (int q = 0; q < ND; q++) qd[q] = 0;
         if (__any(act && on_cur != colm)) {
         Ent aL, aR, aI;
 #pragma unroll
