@@ -38,20 +38,26 @@ typedef unsigned __attribute__((address_space(1))) *g_u32p;
 typedef uint8_t __attribute__((address_space(1))) *g_u8p;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned long long u64;
+
 struct WsLaunch {
-    u32x4 *mail;            // granules; a job's part starts at OptJob::ws_mail
+    u64 *mail;              // hand-off units {data dword, tag}; a job's part starts at OptJob::ws_mail
     unsigned tagbase;       // epoch << 16
     unsigned *err;          // page-locked host word, set when a poll gave up
     int smax;               // grid = jobs * smax single-wave workgroups
 };
 
-__device__ __forceinline__ u32x4 ws_mail_load(const u32x4 *p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+// One hand-off unit = 8 bytes {one dword of output bytes, tag}, read and written by ONE relaxed system-scope atomic
+// (`global_load/store_dwordx2 sc0 sc1`): single-copy atomic, so a unit whose tag matches carries that row's bytes, and
+// -- unlike an inline-asm load -- the compiler knows these loads: a request that is in flight across the loop's back edge
+// cannot be copied or spilled before it has landed (a first version used 16-byte asm loads into a loop-carried register
+// quad; when the register allocator put a copy between the load and its wait, a copy that straddled the arrival took
+// the new tag with the previous row's bytes).
+__device__ __forceinline__ u64 ws_mail_load(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ void ws_mail_store(u32x4 *p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void ws_mail_store(u64 *p, unsigned data, unsigned tag) {
+    __hip_atomic_store(p, ((u64)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // 16-bit halves added straight out of the packed pairs (SDWA operand selects)
@@ -148,16 +154,17 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         return e;
     };
 
-    // mailbox slots of this strip's two boundaries (granule index = ((boundary * h + row) * HL + lane-in-boundary))
-    u32x4 *mail_out = nullptr;
-    const u32x4 *mail_in = nullptr;
+    // mailbox slots of this strip's two boundaries (unit index = (((boundary * h + row) * HL + lane-in-boundary) * ND + dword)
+    u64 *mail_out = nullptr;
+    const u64 *mail_in = nullptr;
     {
-        u32x4 *base = L.mail + J.ws_mail;
+        u64 *base = L.mail + J.ws_mail;
         const int lane_o = producer ? (x0 - (XEc - 4 * HL)) >> 2 : 0;
         const int lane_i = lhalo ? l : 0;
-        mail_out = base + (size_t)min(strip, max(J.ws_S - 2, 0)) * h * HL + lane_o;
-        mail_in = base + (size_t)max(strip - 1, 0) * h * HL + lane_i;
+        mail_out = base + ((size_t)min(strip, max(J.ws_S - 2, 0)) * h * HL + lane_o) * ND;
+        mail_in = base + ((size_t)max(strip - 1, 0) * h * HL + lane_i) * ND;
     }
+    const size_t mrow = (size_t)HL * ND;           // units per row of a boundary
 
     // selection nibble (bit i: column x0 + i selected = mask bit set, optional inversion, inside the image) -> 0xFF bytes
     auto nib_bytes = [&](unsigned nib) { return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u; };
@@ -317,7 +324,9 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     //       row in those very registers;
     //   the neighbour's granule: requested behind the vertical update, used at the top of the next row.
     unsigned mw, e_px[ND], lv_px[ND], ol[ND];
-    u32x4 mbp = {0, 0, 0, 0};
+    u64 mbp[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++) mbp[q] = 0;
     mw = load_mw(n - 1);
     load_px(n - 1, e_px);
     load_px(0, lv_px);
@@ -327,28 +336,45 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
 
     for (int y = 0; y < h; y++) {
         // ---- the previous output row leaves: store, hand-off ----
+        // Everything requested during the previous row is waited for HERE, before this row's stores go out: vmcnt retires in
+        // order, so a wait that falls behind the stores (the compiler puts one in front of the first instruction that
+        // touches a register with a load pending -- even a write) also waits for their write acknowledgements, a memory round
+        // trip of the write-through hand-off store in every row.
+        {
+            asm volatile("" : "+v"(mw) : : "memory");
+#pragma unroll
+            for (int q = 0; q < ND; q++) asm volatile("" : "+v"(e_px[q]), "+v"(lv_px[q]), "+v"(ol[q]), "+v"(mbp[q]) : : "memory");
+        }
         if (y >= 1) {
             const unsigned tag_prev = L.tagbase + (unsigned)(y - 1);
-            // (the wait for the neighbour's granule comes BEFORE this row's stores: vmcnt retires in order, behind them
-            // it would wait for their write acknowledgements as well)
             if (strip > 0) {
                 // the neighbour's output row y-1 (asked for during the previous row): poll until it is this launch's
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
+                auto stale = [&]() {
+                    bool st = false;
+#pragma unroll
+                    for (int q = 0; q < ND; q++) st |= (unsigned)(mbp[q] >> 32) != tag_prev;
+                    return __any(lhalo && st);
+                };
                 int spins = 0;
-                while (__any(lhalo && mbp.w != tag_prev)) {
+                while (stale()) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)(y - 1) * HL) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbp) : : "memory");
+                    if (lhalo) {
+#pragma unroll
+                        for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)(y - 1) * mrow + q);
+                    }
                     if (++spins > (1 << 22)) { if (l == 0) __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 }
             }
             store_row(y - 1, prev);
-            if (producer)
-                ws_mail_store(mail_out + (size_t)(y - 1) * HL, u32x4{prev[0], ND > 1 ? prev[ND > 1 ? 1 : 0] : 0u, ND > 2 ? prev[ND > 2 ? 2 : 0] : 0u, tag_prev});
+            if (producer) {
+#pragma unroll
+                for (int q = 0; q < ND; q++) ws_mail_store(mail_out + (size_t)(y - 1) * mrow + q, prev[q], tag_prev);
+            }
             if (strip > 0) {
                 hslot = hslot == n ? 0 : hslot + 1;
                 if (lhalo) {
-                    prev[0] = mbp.x; if constexpr (ND > 1) prev[1] = mbp.y; if constexpr (ND > 2) prev[2] = mbp.z;
+#pragma unroll
+                    for (int q = 0; q < ND; q++) prev[q] = (unsigned)mbp[q];
                     // row y-n-1 comes back out of the ring (the slot after the one row y-1 goes into), row y-1 goes in
                     const int sr = hslot == n ? 0 : hslot + 1;
                     unsigned *pr = hring + (sr * HL + l) * ND, *pw = hring + (hslot * HL + l) * ND;
@@ -369,7 +395,10 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             asm volatile("" : "+v"(vo_m), "+v"(vo_px));
             load_px(y, prev);
             mw = load_mw(y + n);
-            if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)min(y, h - 1) * HL) : "memory");
+            if (lhalo) {
+#pragma unroll
+                for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)min(y, h - 1) * mrow + q);
+            }
 #pragma unroll
             for (int q = 0; q < ND; q++) prev[q] &= pxm[q];
             continue;
@@ -454,7 +483,10 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             load_px(yn + n - 1, e_px);
             load_px(yn - n - 1, lv_px);
             load_out(yn - n - 1, ol);
-            if (lhalo) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(mbp) : "v"(mail_in + (size_t)min(y, h - 1) * HL) : "memory");
+            if (lhalo) {
+#pragma unroll
+                for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)min(y, h - 1) * mrow + q);
+            }
         }
         if (y <= n) {
             asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
@@ -648,16 +680,16 @@ int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d
                        OptMail *mail, double alg) {
     int smax = 1;
     bool generic = false;
-    size_t granules = 16;                                   // first 256 bytes: the error word
+    size_t granules = 32;                                   // (first 256 bytes unused) -- counted in 8-byte units
     for (int i = 0; i < njobs; i++) {
         OptJob &j = h_jobs[i];
         ws_geometry(w, j.n, &j.ws_S, &j.ws_clb);
         j.ws_mail = granules;
-        granules += (size_t)std::max(j.ws_S - 1, 0) * h * ((j.n + 3) >> 2);
+        granules += (size_t)std::max(j.ws_S - 1, 0) * h * ((j.n + 3) >> 2) * c;
         smax = std::max(smax, j.ws_S);
         if (j.n != 3 && j.n != 10) generic = true;
     }
-    const size_t need = granules * sizeof(u32x4);
+    const size_t need = granules * sizeof(u64);
     if (need > mail->bytes) {
         HIP_TRY(hipStreamSynchronize(s));
         TRY(mail->buf.alloc(ctx, need + need / 8));
@@ -671,7 +703,7 @@ int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d
     mail->epoch++;
     HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
     WsLaunch L;
-    L.mail = mail->buf.as<u32x4>();
+    L.mail = mail->buf.as<u64>();
     L.tagbase = mail->epoch << 16;
     L.err = mail->err;
     L.smax = smax;

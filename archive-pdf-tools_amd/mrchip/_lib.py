@@ -203,6 +203,7 @@ class Context:
 
     def prof_enable(self, on=True):
         check(load().mrchip_prof_enable(self.handle, 1 if on else 0))
+        self.prof_on = bool(on)
 
     def prof_reset(self):
         check(load().mrchip_prof_reset(self.handle))

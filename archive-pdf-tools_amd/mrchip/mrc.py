@@ -729,6 +729,57 @@ def _image_to_array(image):
     return np.ascontiguousarray(arr), gray
 
 
+# kernels (mrchip_prof_* names) behind each of the reference's timing keys (mrc.py:363, 270, 308, 313, 327, 390, 418, 434,
+# 452, 468).  The radix-select passes of the noise estimate serve the page estimate and the hOCR boxes' estimates alike;
+# they are booked on est_1.
+_STAGE_KERNELS = {
+    'grey_conversion': ('luma601',),
+    'hocr_mask_gen': ('sauvola_boxes', 'hocr_commit', 'dwt_dd_f64'),
+    'est_1': ('dwt_dd_f32', 'median_reset', 'median_hist', 'median_scan'),
+    'blur_1': ('gauss_fused', 'gauss_v', 'gauss_h'),
+    'threshold': ('sauvola',),
+    'fast_denoise': ('denoise_pack', 'denoise_solve', 'denoise_reconcile', 'denoise_unpack', 'denoise_jacobi', 'mask_pack_bits'),
+    'partial_blur': ('optimise_rgb', 'optimise_gray'),
+    'downsample': ('thumb_reduce', 'thumb_resize_h', 'thumb_resize_v', 'thumb_resize_mm'),
+}
+
+
+class _StageClock:
+    """Per-stage seconds for timing_data: the GPU time of the kernels behind each key, from the library's HIP-event
+    profile (mrchip_prof_*), taken as differences of the running totals so that a caller's own profiling is left alone."""
+
+    def __init__(self, ctx, on):
+        self.ctx, self.on = ctx, on
+        self.was = getattr(ctx, 'prof_on', False)
+        if on:
+            if not self.was:
+                ctx.prof_enable(True)
+            self.last = ctx.prof_report()
+
+    def lap(self):
+        """seconds of GPU time per stage since the previous lap"""
+        if not self.on:
+            return {}
+        now = self.ctx.prof_report()
+        out = {}
+        for key, names in _STAGE_KERNELS.items():
+            out[key] = sum(now[k]['ms'] - self.last.get(k, {'ms': 0.0})['ms'] for k in names if k in now) * 1e-3
+        self.last = now
+        return out
+
+    def close(self):
+        if self.on and not self.was:
+            self.ctx.prof_enable(False)
+
+
+def _book(timing_data, wall, main_key, entries):
+    """append (key, seconds) in the reference's order: every key gets the GPU time of its kernels, the key that stands
+    for the phase also the rest of the phase's wall time (host work, PCIe, launch gaps), so the keys add up to `wall`"""
+    rest = max(0.0, wall - sum(sec for _, sec in entries))
+    for key, sec in entries:
+        timing_data.append((key, sec + (rest if key == main_key else 0.0)))
+
+
 def create_mrc_hocr_components(image, hocr_word_data,
                                dpi=None,
                                downsample=None,
@@ -743,6 +794,7 @@ def create_mrc_hocr_components(image, hocr_word_data,
     channels = 1 if image_arr.ndim == 2 else 3
     ctx = ctx or _lib.default_context()
     page = _Page(ctx, width_, height_, channels)
+    clock = _StageClock(ctx, timing_data is not None)
     try:
         t = time()
         page.upload(image_arr)
@@ -753,22 +805,23 @@ def create_mrc_hocr_components(image, hocr_word_data,
         sigma_est = page.sigma()
         now = time()
         if timing_data is not None:
-            # the GPU runs these stages back to back; the split of the elapsed time keeps the
-            # reference's keys and order (mrc.py:363, 270, 308)
-            if channels == 3:
-                timing_data.append(('grey_conversion', 0.0))
-            timing_data.append(('hocr_mask_gen', now - t))
-            timing_data.append(('est_1', 0.0))
+            # the reference's keys and order (mrc.py:363, 270, 308); each key = the GPU time of its kernels, the upload, the
+            # box parsing and the wait for the estimate go to hocr_mask_gen
+            g = clock.lap()
+            _book(timing_data, now - t, 'hocr_mask_gen',
+                  ([('grey_conversion', g['grey_conversion'])] if channels == 3 else []) +
+                  [('hocr_mask_gen', g['hocr_mask_gen']), ('est_1', g['est_1'])])
         t = time()
         page.mask_finish(sigma_est, denoise_mask == DENOISE_FAST)
         mask_arr = page.download_mask()
         now = time()
         if timing_data is not None:
-            if sigma_est > 1.0:
-                timing_data.append(('blur_1', 0.0))                           # mrc.py:313
-            timing_data.append(('threshold', now - t))                        # mrc.py:327
-            if denoise_mask == DENOISE_FAST:
-                timing_data.append(('fast_denoise', 0.0))                     # mrc.py:390
+            g = clock.lap()
+            # (the commit of the hOCR-box decisions runs in this phase: its kernels stay on the threshold key's remainder)
+            _book(timing_data, now - t, 'threshold',
+                  ([('blur_1', g['blur_1'])] if sigma_est > 1.0 else []) +                      # mrc.py:313
+                  [('threshold', g['threshold'])] +                                             # mrc.py:327
+                  ([('fast_denoise', g['fast_denoise'])] if denoise_mask == DENOISE_FAST else []))   # mrc.py:390
         if denoise_mask == DENOISE_BREGMAN:                                   # mrc.py:391-394, on the host
             t = time()
             mask_arr = denoise_bregman(mask_arr)
@@ -780,6 +833,7 @@ def create_mrc_hocr_components(image, hocr_word_data,
         yield mask_arr
 
         sizes = None
+        glay = {}
         for is_bg, ds, key in ((0, fg_downsample, 'fg'), (1, bg_downsample, 'bg')):
             t = time()
             if sizes is None:
@@ -791,14 +845,23 @@ def create_mrc_hocr_components(image, hocr_word_data,
             arr = page.download_layer(is_bg, ow, oh)
             now = time()
             if timing_data is not None:
-                timing_data.append(('%s_partial_blur' % key, now - t))        # mrc.py:418, 452
+                if not glay:
+                    # one optimise launch holds both page-layers (equal pixel counts: half each); the thumbnail kernels of
+                    # the layers that are downsampled likewise
+                    g = clock.lap()
+                    nds = (fg_downsample is not None) + (bg_downsample is not None)
+                    glay = {'blur': g['partial_blur'] / 2, 'ds': g['downsample'] / max(nds, 1)}
+                # mrc.py:418, 434, 452, 468; the wall time of this yield (fg: the joint launch and its download, bg: its
+                # download) beyond this layer's kernels stays on the partial_blur key
+                _book(timing_data, max(now - t, glay['blur'] + (glay['ds'] if ds is not None else 0.0)),
+                      '%s_partial_blur' % key,
+                      [('%s_partial_blur' % key, glay['blur'])] + ([('%s_downsample' % key, glay['ds'])] if ds is not None else []))
             if ds is not None:
                 if too_small and errors is not None:
                     errors.add(RECODE_RUNTIME_WARNING_TOO_SMALL_TO_DOWNSAMPLE)  # mrc.py:429-431
-                if timing_data is not None:
-                    timing_data.append(('%s_downsample' % key, 0.0))          # mrc.py:434, 468
             yield arr
     finally:
+        clock.close()
         page.close()
     return
 

@@ -206,3 +206,35 @@ def test_more_boxes_than_a_grid_dimension():
     O.create_hocr_mask(img, exp, boxes, dpi=None, decisions=edec)
     assert list(dec) == list(edec)
     assert np.array_equal(mask.view(np.bool_), exp), int((mask.view(np.bool_) != exp).sum())
+
+
+def test_timing_data_carries_measured_stage_times():
+    """five of the reference's timing keys used to be a literal 0.0.  Every key now carries the GPU time
+    of the kernels behind it (mrchip_prof_*), the phase's host / PCIe remainder stays on the key that stands for the phase,
+    keys and order as the reference appends them (mrc.py:363, 270, 308, 313, 327, 390, 418, 434, 452, 468)."""
+    import time
+    img, hocr = synth.synth_page(1200, 900, 3, seed=21, noise_sigma=6.0, line_div=30)
+    ctx = _lib.default_context()
+    for rep in range(2):                       # the second pass is warm
+        td = []
+        t0 = time.time()
+        for _ in mrc.create_mrc_hocr_components(img, hocr, bg_downsample=3, fg_downsample=2, denoise_mask='fast', timing_data=td):
+            pass
+        wall = time.time() - t0
+    keys = [k for k, _ in td]
+    assert keys == ['grey_conversion', 'hocr_mask_gen', 'est_1', 'blur_1', 'threshold', 'fast_denoise', 'fg_partial_blur',
+                    'fg_downsample', 'bg_partial_blur', 'bg_downsample']
+    vals = dict(td)
+    assert all(v > 0.0 for v in vals.values()), vals                    # every stage ran kernels: none of them is free
+    assert sum(vals.values()) <= wall * 1.05                            # and together they are the generator's wall time
+    assert vals['grey_conversion'] < vals['hocr_mask_gen'] and vals['est_1'] < wall
+    assert not getattr(ctx, 'prof_on', False)                           # the profile is switched off again
+    # a caller's own profiling session is left running
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    td2 = []
+    for _ in mrc.create_mrc_hocr_components(img, hocr, bg_downsample=3, denoise_mask='fast', timing_data=td2):
+        pass
+    assert ctx.prof_on and 'optimise_rgb' in ctx.prof_report()
+    ctx.prof_enable(False)
+    assert [k for k, _ in td2] == [k for k in keys if k != 'fg_downsample']
