@@ -28,6 +28,7 @@
 //
 // Algorithmic bytes: (1 + 2C) * w * h per call.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mrchip_internal.h"
 
@@ -82,6 +83,20 @@ __device__ __forceinline__ unsigned ws_add_dw1(unsigned a, unsigned b) {      //
     return r;
 }
 
+// a lane's 4 pixels of a row: one register triple (RGB) or one register (gray), loaded by ONE asm statement
+template <int C> struct PxV;
+template <> struct PxV<3> { typedef unsigned T __attribute__((ext_vector_type(3))); };
+template <> struct PxV<1> { typedef unsigned T; };
+template <int C>
+__device__ __forceinline__ void px_load_async(typename PxV<C>::T &r, unsigned off, const uint8_t *base) {
+    if constexpr (C == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    else asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+}
+template <int C>
+__device__ __forceinline__ unsigned px_dword(const typename PxV<C>::T &r, int q) {
+    if constexpr (C == 3) return r[q]; else return r;
+}
+
 // NCT: n_size as a compile-time constant (3 and 10, the reference's two call sites mrc.py:413/415, 447/449) or -1 for
 // a run-time n <= 11.  16-bit lane capacity as in k_optimise.hip: one FIR accumulator up to n = 8 (and FIR + IIR in one
 // for n <= 7), two half-window accumulators up to n = 11.
@@ -93,6 +108,7 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     constexpr bool SUMROW = (NCT >= 1 && NCT <= 7);
     constexpr int NH = (NCT >= 0 && NCT <= 8) ? 1 : 2;
     constexpr int HWORDS = NCT >= 0 ? (4 * (2 * NCT + 1) + 31) / 32 : 3;      // mask shift register, 2n + 1 nibbles
+    typedef typename PxV<C>::T pxv_t;
     const uint8_t *__restrict__ img = J.img;
     uint8_t *out = J.out;
     const unsigned *mbits = J.mbits;
@@ -155,16 +171,19 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     };
 
     // mailbox slots of this strip's two boundaries (unit index = (((boundary * h + row) * HL + lane-in-boundary) * ND + dword)
-    u64 *mail_out = nullptr;
-    const u64 *mail_in = nullptr;
+    // (uniform base of the boundary + the lane's 32-bit unit offset: one register per direction, not a 64-bit pointer)
+    u64 *mail_out_b = nullptr;
+    const u64 *mail_in_b = nullptr;
+    unsigned mo_off = 0, mi_off = 0;
     {
         u64 *base = L.mail + J.ws_mail;
-        const int lane_o = producer ? (x0 - (XEc - 4 * HL)) >> 2 : 0;
-        const int lane_i = lhalo ? l : 0;
-        mail_out = base + ((size_t)min(strip, max(J.ws_S - 2, 0)) * h * HL + lane_o) * ND;
-        mail_in = base + ((size_t)max(strip - 1, 0) * h * HL + lane_i) * ND;
+        mo_off = (unsigned)((producer ? (x0 - (XEc - 4 * HL)) >> 2 : 0) * ND);
+        mi_off = (unsigned)((lhalo ? l : 0) * ND);
+        mail_out_b = base + (size_t)min(strip, max(J.ws_S - 2, 0)) * h * HL * ND;
+        mail_in_b = base + (size_t)max(strip - 1, 0) * h * HL * ND;
     }
     const size_t mrow = (size_t)HL * ND;           // units per row of a boundary
+    auto mail_out = [&](int row, int q) { return (mail_out_b + (size_t)row * mrow + q) + mo_off; };
 
     // selection nibble (bit i: column x0 + i selected = mask bit set, optional inversion, inside the image) -> 0xFF bytes
     auto nib_bytes = [&](unsigned nib) { return (__umul24(nib, 0x00204081u) & 0x01010101u) * 255u; };
@@ -239,13 +258,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         gc_u32p pm = (gc_u32p)((const uint8_t *)(mbits + (size_t)yc * mwpr) + vo_m);
         return pm[0];
     };
-    auto load_out = [&](int yy, unsigned (&o)[ND]) {
-        const int yc = min(max(yy, 0), h - 1);
-        gc_u32p p = (gc_u32p)((out + (size_t)yc * opitch) + vo_px);
-#pragma unroll
-        for (int q = 0; q < ND; q++) o[q] = p[q];
-    };
-
     // "Rare" pixels decide how much of a row has to be done: the selected ones of a sparse layer (fg: the ink), the
     // unselected ones of a dense layer (bg: the inverted mask).  rare_rows counts the rows of the current FIR window
     // [y-n, y+n) that hold a rare pixel in this wave's columns (halo included).  While it is zero,
@@ -285,22 +297,19 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     unsigned *hring = iirA + (size_t)nelem * EW;
     int hslot = 0;                                   // slot of row y-1 (uniform)
 
+    // One store instruction per row whatever the lane: the last column group of a row may reach up to 3 columns past the
+    // image -- into the row's padding (every device image has pitch >= row bytes + 64, mrchip_internal.h), with zeros
+    // (the output registers are masked to the image).  A byte-wise tail would make the number of memory operations of a
+    // row data-dependent, and the compiler's counted waits (vmcnt) fall back to "everything" behind such a branch.
     auto store_row = [&](int yy, const unsigned (&res)[ND]) {
         if (!act) return;
         uint8_t *o = out + (size_t)yy * opitch + (size_t)x0 * C;
-        if (x0 + P <= XE) {
 #pragma unroll
-            for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
-        } else {
-            const int nbytes = (XE - x0) * C;
-#pragma unroll
-            for (int j = 0; j < P * C; j++)
-                if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(res[j >> 2] >> (8 * (j & 3)));
-        }
+        for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
     };
     // (y - ys) * (x - xs) as a float per column, and -- for the short path of a sparse layer, where it is the whole count
     // -- its reciprocal and the quotient's offset: they only change while the window still grows (rows 0..n)
-    float kf[P], rcK[SUMROW ? P : 1], qoffK[SUMROW ? P : 1];
+    float kf[P], rcK[SUMROW ? P : 1];
 #pragma unroll
     for (int i = 0; i < P; i++) kf[i] = 0.0f;
     auto set_kf = [&](int yy) {
@@ -309,72 +318,109 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             kf[i] = (float)(min(yy, n) * min(max(x0 + i, 0), n));          // (y - ys) * (x - xs)
             if constexpr (SUMROW) {
                 rcK[i] = __builtin_amdgcn_rcpf(__builtin_fmaxf(kf[i], 1.0f));
-                qoffK[i] = __builtin_fmaf(rcK[i], 0.5f, -0.5f);
             }
         }
     };
     set_kf(0);
 
-    // ONE set of input registers: a row's inputs are requested as soon as the previous row has used the registers they
-    // land in, and waited for where they are used --
-    //   mw / e / lv / ol (entering mask word, entering and leaving image row, leaving output row): used by the vertical
-    //       update at the top of a row, re-requested right behind it (3/4 of a row ahead);
-    //   the current image row: requested into the registers of `prev` once the previous output row has been stored,
-    //       handed on and added to the IIR sums; used by the merge at the bottom of the row, which leaves the new output
-    //       row in those very registers;
-    //   the neighbour's granule: requested behind the vertical update, used at the top of the next row.
-    unsigned mw, e_px[ND], lv_px[ND], ol[ND];
-    u64 mbp[ND];
+    // TWO sets of input registers, used alternately (the row loop is unrolled by two): row y consumes one set and requests
+    // the inputs of row y + 2 into the same registers as soon as it is done with them -- every request has more than a whole
+    // row to land.  One row ahead the kernel ran at the pace of the memory latency (a lone wave: ~1.5 us per row, of which
+    // ~0.4 us are arithmetic), and the compiler's own wait counts collapse to "everything" behind this loop's branches and
+    // polls.  So the loads and their waits are written by hand, as in k_sauvola.hip: a load is an asm statement whose output
+    // the compiler takes for ready, every use sits behind an asm `s_waitcnt vmcnt(N)` that names the registers (which also
+    // pins the order).  vmcnt retires in order and EVERY row issues the same sequence of memory operations
+    //     [row store] [hand-off stores: 0 or U] [mw, e, lv, ol, U hand-off units] [c]
+    // whatever its mode (dormant, short, general), so N = the operations issued after the one needed, counted for a strip
+    // without hand-off stores (more operations in flight than counted -- the stores of a producer, a poll, the loads of a
+    // wake-up -- only make a wait stricter).  Each request has ONE site per set, the sets are distinct variables of the two
+    // unrolled row bodies, and the listing is checked for spills: a copy of a register between its load and its wait would
+    // read the old contents.
+    constexpr int U = ND;                              // hand-off units per lane and row
+    constexpr int WAIT_TOP = 7 + U;                    // after row y-2's requests: c(y-2); store, requests, c of row y-1
+    constexpr int WAIT_C = 11 + 2 * U;                 // after c(y-2): row y-1 whole; store and requests of row y
+    struct In {
+        unsigned mw;
+        pxv_t e, lv, ol, c;
+        u64 mbp[U];
+    };
+    In SA, SB;
+    auto request_top = [&](In &S, int ys) {            // inputs of row ys but its current image row
+        const int ye = min(max(ys + n - 1, 0), h - 1), yl = min(max(ys - n - 1, 0), h - 1), yg = min(max(ys - 1, 0), h - 1);
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(S.mw) : "v"(vo_m), "s"((const uint8_t *)(mbits + (size_t)ye * mwpr)) : "memory");
+        px_load_async<C>(S.e, vo_px, img + (size_t)ye * ipitch);
+        px_load_async<C>(S.lv, vo_px, img + (size_t)yl * ipitch);
+        px_load_async<C>(S.ol, vo_px, out + (size_t)yl * opitch);
+        // (every lane asks, lanes outside the left halo for the halo's first unit)
 #pragma unroll
-    for (int q = 0; q < ND; q++) mbp[q] = 0;
-    mw = load_mw(n - 1);
-    load_px(n - 1, e_px);
-    load_px(0, lv_px);
+        for (int q = 0; q < U; q++)
+            asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(S.mbp[q]) : "v"(mi_off * 8u), "s"(mail_in_b + (size_t)yg * mrow + q) : "memory");
+    };
+    auto request_c = [&](In &S, int ys) {
+        px_load_async<C>(S.c, vo_px, img + (size_t)min(max(ys, 0), h - 1) * ipitch);
+    };
+    // (`steady` is a compile-time tag: a run-time choice between two wait statements that name the same registers makes
+    // the compiler merge two versions of them -- with copies of registers whose loads are still in flight)
+    auto wait_top = [&](In &S, auto steady_t) {
+        if constexpr (decltype(steady_t)::value) {
+            if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(S.mw), "+v"(S.e), "+v"(S.lv), "+v"(S.ol), "+v"(S.mbp[0]), "+v"(S.mbp[U > 1 ? 1 : 0]) : "n"(WAIT_TOP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%5)" : "+v"(S.mw), "+v"(S.e), "+v"(S.lv), "+v"(S.ol), "+v"(S.mbp[0]) : "n"(WAIT_TOP) : "memory");
+            if constexpr (U == 3) asm volatile("" : "+v"(S.mbp[U > 2 ? 2 : 0]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.mw), "+v"(S.e), "+v"(S.lv), "+v"(S.ol), "+v"(S.mbp[0]) : : "memory");
+            if constexpr (U == 3) asm volatile("" : "+v"(S.mbp[1]), "+v"(S.mbp[U > 2 ? 2 : 0]) : : "memory");
+        }
+    };
+    auto wait_c = [&](In &S, auto steady_t) {
+        if constexpr (decltype(steady_t)::value) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(S.c) : "n"(WAIT_C) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.c) : : "memory");
+    };
 #pragma unroll
-    for (int q = 0; q < ND; q++) ol[q] = 0;
+    for (int q = 0; q < U; q++) { SA.mbp[q] = 0; SB.mbp[q] = 0; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the warm-up's loads are the compiler's: start from zero
+    request_top(SA, 0); request_c(SA, 0);
+    request_top(SB, 1); request_c(SB, 1);
     bool dormant = false;
 
-    for (int y = 0; y < h; y++) {
-        // ---- the previous output row leaves: store, hand-off ----
-        // Everything requested during the previous row is waited for HERE, before this row's stores go out: vmcnt retires in
-        // order, so a wait that falls behind the stores (the compiler puts one in front of the first instruction that
-        // touches a register with a load pending -- even a write) also waits for their write acknowledgements, a memory round
-        // trip of the write-through hand-off store in every row.
-        {
-            asm volatile("" : "+v"(mw) : : "memory");
+    auto do_row = [&](const int y, In &S, auto steady) {
+        // ---- this row's set has landed (waited for BEFORE this row's stores go out: behind them the wait would include
+        // their write acknowledgements -- a memory round trip of the write-through hand-off store in every row) ----
+        wait_top(S, steady);
+        unsigned e_px[ND], lv_px[ND], ol[ND];
 #pragma unroll
-            for (int q = 0; q < ND; q++) asm volatile("" : "+v"(e_px[q]), "+v"(lv_px[q]), "+v"(ol[q]), "+v"(mbp[q]) : : "memory");
-        }
+        for (int q = 0; q < ND; q++) { e_px[q] = px_dword<C>(S.e, q); lv_px[q] = px_dword<C>(S.lv, q); ol[q] = px_dword<C>(S.ol, q); }
+        const unsigned mw = S.mw;
         if (y >= 1) {
             const unsigned tag_prev = L.tagbase + (unsigned)(y - 1);
             if (strip > 0) {
-                // the neighbour's output row y-1 (asked for during the previous row): poll until it is this launch's
+                // the neighbour's output row y-1 (asked for two rows ago): poll until it is this launch's
                 auto stale = [&]() {
                     bool st = false;
 #pragma unroll
-                    for (int q = 0; q < ND; q++) st |= (unsigned)(mbp[q] >> 32) != tag_prev;
+                    for (int q = 0; q < U; q++) st |= (unsigned)(S.mbp[q] >> 32) != tag_prev;
                     return __any(lhalo && st);
                 };
                 int spins = 0;
                 while (stale()) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (lhalo) {
 #pragma unroll
-                        for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)(y - 1) * mrow + q);
-                    }
+                    for (int q = 0; q < U; q++)
+                        asm volatile("global_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(S.mbp[q]) : "v"(mi_off * 8u), "s"(mail_in_b + (size_t)(y - 1) * mrow + q) : "memory");
+                    if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.mbp[0]), "+v"(S.mbp[U > 1 ? 1 : 0]), "+v"(S.mbp[U > 2 ? 2 : 0]) : : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.mbp[0]) : : "memory");
                     if (++spins > (1 << 22)) { if (l == 0) __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 }
             }
             store_row(y - 1, prev);
             if (producer) {
 #pragma unroll
-                for (int q = 0; q < ND; q++) ws_mail_store(mail_out + (size_t)(y - 1) * mrow + q, prev[q], tag_prev);
+                for (int q = 0; q < U; q++) ws_mail_store(mail_out(y - 1, q), prev[q], tag_prev);
             }
             if (strip > 0) {
                 hslot = hslot == n ? 0 : hslot + 1;
                 if (lhalo) {
 #pragma unroll
-                    for (int q = 0; q < ND; q++) prev[q] = (unsigned)mbp[q];
+                    for (int q = 0; q < ND; q++) prev[q] = (unsigned)S.mbp[q];
                     // row y-n-1 comes back out of the ring (the slot after the one row y-1 goes into), row y-1 goes in
                     const int sr = hslot == n ? 0 : hslot + 1;
                     unsigned *pr = hring + (sr * HL + l) * ND, *pw = hring + (hslot * HL + l) * ND;
@@ -388,25 +434,13 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         // ---- the entering row's selection; dense layer: may this row be a plain copy? ----
         const unsigned nib_e = (y + n - 1 < h) ? nib_of_word(mw) : 0u;
         const bool rare_e = (y + n - 1 < h) && rare_any(nib_e);
+        bool copyrow = false;
 #ifndef MRCHIP_WS_NODORMANT
-        if (!sparse && rare_rows == 0 && !rare_e) {
-            // DORMANT row: no unselected pixel in rows [y-n, y+n) of this wave's columns -> out = img
-            dormant = true;
-            asm volatile("" : "+v"(vo_m), "+v"(vo_px));
-            load_px(y, prev);
-            mw = load_mw(y + n);
-            if (lhalo) {
-#pragma unroll
-                for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)min(y, h - 1) * mrow + q);
-            }
-#pragma unroll
-            for (int q = 0; q < ND; q++) prev[q] &= pxm[q];
-            continue;
-        }
-        if (dormant) {
+        copyrow = !sparse && rare_rows == 0 && !rare_e;
+        if (copyrow) dormant = true;          // DORMANT row: no unselected pixel in rows [y-n, y+n) of this wave's columns -> out = img
+        else if (dormant) {
             // ---- WAKE UP: the state this row would have found had the sums been kept -- FIR sums of rows [y-1-n, y-1+n),
-            // IIR sums of rows [y-1-n, y-1) (out = img on all of them: no unselected pixel), the mask history, the inputs
-            // the dormant rows did not request ----
+            // IIR sums of rows [y-1-n, y-1) (out = img on all of them: no unselected pixel) and the mask history ----
             dormant = false;
 #pragma unroll
             for (int i = 0; i < P; i++)
@@ -434,69 +468,58 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
 #pragma unroll
             for (int k = 0; k < HWORDS; k++) hist[k] = 0;
             for (int k = 2 * n; k >= 0; k--) { const int r = y + n - 2 - k; hist_push((r >= 0 && r < h) ? coln : 0u); }
-            load_px(y - n - 1, lv_px);
-            if (!lhalo) {
-#pragma unroll
-                for (int q = 0; q < ND; q++) ol[q] = lv_px[q];       // out = img on the leaving row (masked where it is used)
-            }
-            load_px(y + n - 1, e_px);
             set_kf(y);
         }
 #endif
-        // ---- the previous output row joins the IIR sums; the current image row is requested into its registers ----
-        if (y >= 1 && n >= 1) {
-            Ent e[P];
-            iir_entries(prev, e);
+        unsigned nib_c = 0;
+        bool shortrow = false;
+        if (!copyrow) {
+            // ---- the previous output row joins the IIR sums ----
+            if (y >= 1 && n >= 1) {
+                Ent e[P];
+                iir_entries(prev, e);
 #pragma unroll
-            for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
-        }
-        // ---- mask: the entering row's nibble goes in, the current and the leaving row's come out ----
-        hist_push(nib_e);
-        const unsigned nib_c = hist_at(n - 1), nib_l = hist_at(2 * n);
-        if (rare_e) rare_rows++;
-        if (y - n - 1 >= 0 && rare_any(nib_l)) rare_rows--;
-        // sparse layer, no selected pixel in rows [y-n, y+n): the short path (needs neither FIR sums nor the image row)
-#ifdef MRCHIP_WS_NOSHORT
-        const bool shortrow = false;
-#else
-        const bool shortrow = SUMROW && sparse && rare_rows == 0;
+                for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+            }
+            // ---- mask: the entering row's nibble goes in, the current and the leaving row's come out ----
+            hist_push(nib_e);
+            nib_c = hist_at(n - 1);
+            const unsigned nib_l = hist_at(2 * n);
+            if (rare_e) rare_rows++;
+            if (y - n - 1 >= 0 && rare_any(nib_l)) rare_rows--;
+            // sparse layer, no selected pixel in rows [y-n, y+n): the short path (needs neither FIR sums nor the image row)
+#ifndef MRCHIP_WS_NOSHORT
+            shortrow = SUMROW && sparse && rare_rows == 0;
 #endif
-        asm volatile("" : "+v"(vo_m), "+v"(vo_px));          // keeps `row base + lane offset` addressing (k_optimise.hip)
-        if (!shortrow) load_px(y, prev);
+            // ---- vertical running sums for row y (wave-uniform row tests) ----
+            if (y + n - 1 < h && n >= 1) fir_apply(e_px, nib_e, true);        // ye = min(h, y+n)
+            if (y - n - 1 >= 0 && n >= 1) {
+                fir_apply(lv_px, nib_l, false);                                // ys = max(0, y-n)
+                unsigned o[ND];
+#pragma unroll
+                for (int q = 0; q < ND; q++) o[q] = ol[q] & pxm[q];
+                Ent e[P];
+                iir_entries(o, e);
+#pragma unroll
+                for (int i = 0; i < P; i++) esub(iirE[i], e[i]);
+            }
+            if (y <= n) {
+                asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
+                set_kf(y);
+            }
+        }
+        // ---- the set's registers (but c) are free in every mode: the inputs of the row after the next, ONE site ----
+        asm volatile("" : "+v"(firE[0].d[0]), "+v"(iirE[0].d[0]) : : "memory");      // (after the last use of e / lv / ol)
+        request_top(S, y + 2);
 
-        // ---- vertical running sums for row y (wave-uniform row tests) ----
-        if (y + n - 1 < h && n >= 1) fir_apply(e_px, nib_e, true);        // ye = min(h, y+n)
-        if (y - n - 1 >= 0 && n >= 1) {
-            fir_apply(lv_px, nib_l, false);                                // ys = max(0, y-n)
-            unsigned o[ND];
-#pragma unroll
-            for (int q = 0; q < ND; q++) o[q] = ol[q] & pxm[q];
-            Ent e[P];
-            iir_entries(o, e);
-#pragma unroll
-            for (int i = 0; i < P; i++) esub(iirE[i], e[i]);
-        }
-        // ---- their registers are free: the next row's inputs ----
-        {
-            const int yn = y + 1;
-            mw = load_mw(yn + n - 1);
-            load_px(yn + n - 1, e_px);
-            load_px(yn - n - 1, lv_px);
-            load_out(yn - n - 1, ol);
-            if (lhalo) {
-#pragma unroll
-                for (int q = 0; q < ND; q++) mbp[q] = ws_mail_load(mail_in + (size_t)min(y, h - 1) * mrow + q);
-            }
-        }
-        if (y <= n) {
-            asm volatile("" ::: "memory");        // a real (wave-uniform) branch: keeps the multiplies out of the steady state
-            set_kf(y);
-        }
         unsigned qd[ND];
 #pragma unroll
         for (int q = 0; q < ND; q++) qd[q] = 0;
-
-        if (shortrow) {
+        if (copyrow) {
+            wait_c(S, steady);
+#pragma unroll
+            for (int q = 0; q < ND; q++) prev[q] = px_dword<C>(S.c, q) & pxm[q];
+        } else if (shortrow) {
             if constexpr (SUMROW) {
                 // ---- short path: T(x) = sum of the IIR column sums of [x-n, x), count = (y-ys)(x-xs) ----
 #pragma unroll
@@ -519,19 +542,18 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
                     } else {
                         fsum[0] = (float)(aL.d[0] & 0xffffu);
                     }
+                    const float qoff = __builtin_fmaf(rcK[i], 0.5f, -0.5f);
 #pragma unroll
                     for (int c = 0; c < C; c++) {
                         const int jb = i * C + c;
-                        qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rcK[i], qoffK[i]), jb & 3, qd[jb >> 2]);
+                        qd[jb >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(fsum[c], rcK[i], qoff), jb & 3, qd[jb >> 2]);
                     }
                     if (i + 1 < P) { eadd(aL, iirE[i]); esub(aL, lds_ld(iirA, i - NCT)); }
                 }
 #pragma unroll
                 for (int q = 0; q < ND; q++) prev[q] = qd[q] & pxm[q];
             }
-            continue;
-        }
-
+        } else {
         // ---- publish: the registers already hold the LDS entry format ----
 #pragma unroll
         for (int i = 0; i < P; i++) {
@@ -622,26 +644,38 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             }
         }
         }
-        // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient: `prev` holds the
-        // current image row (requested at the top of this row) and becomes the output row
+        // masked pixels keep the image value (new_img = np.copy(img)), the others take the quotient
         {
+            wait_c(S, steady);
             const unsigned on = on_cur;
             if constexpr (C == 3) {
                 const unsigned e0 = __builtin_amdgcn_perm(0u, on, 0x01000000u), e1 = __builtin_amdgcn_perm(0u, on, 0x02020101u),
                                e2 = __builtin_amdgcn_perm(0u, on, 0x03030302u);
-                prev[0] = ((prev[0] & e0) | (qd[0] & ~e0)) & pxm[0];
-                prev[1] = ((prev[1] & e1) | (qd[1] & ~e1)) & pxm[1];
-                prev[2] = ((prev[2] & e2) | (qd[2] & ~e2)) & pxm[2];
+                prev[0] = ((px_dword<C>(S.c, 0) & e0) | (qd[0] & ~e0)) & pxm[0];
+                prev[1] = ((px_dword<C>(S.c, 1) & e1) | (qd[1] & ~e1)) & pxm[1];
+                prev[2] = ((px_dword<C>(S.c, 2) & e2) | (qd[2] & ~e2)) & pxm[2];
             } else {
-                prev[0] = ((prev[0] & on) | (qd[0] & ~on)) & pxm[0];
+                prev[0] = ((px_dword<C>(S.c, 0) & on) | (qd[0] & ~on)) & pxm[0];
             }
         }
+        }
+        // ---- the current image row of the row after the next, ONE site (a short row never looked at its own) ----
+        asm volatile("" : "+v"(prev[0]), "+v"(prev[ND - 1]) : : "memory");
+        request_c(S, y + 2);
+    };
+    // rows 0 and 1 wait for everything (their predecessors are not whole rows), the rest with the counts above
+    do_row(0, SA, std::false_type{});
+    if (h > 1) do_row(1, SB, std::false_type{});
+    for (int y = 2; y < h; y += 2) {
+        do_row(y, SA, std::true_type{});
+        if (y + 1 < h) do_row(y + 1, SB, std::true_type{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last requests (rows past the image) land before the registers are reused
     if (h >= 1) store_row(h - 1, prev);
 }
 
 #ifndef MRCHIP_WS_WAVES
-#define MRCHIP_WS_WAVES 4
+#define MRCHIP_WS_WAVES 3
 #endif
 
 // grid = jobs * smax single-wave workgroups: job = block / smax, strip = block % smax (left strips first)
@@ -669,9 +703,14 @@ void ws_geometry(int w, int n, int *S, int *clb) {
     *clb = cdiv(w4, *S);
 }
 
+// Opt-in (MRCHIP_OPT_WS=1): measured on MI355X this schedule does not beat the workgroup schedule of k_optimise.hip yet
+// (256 page-layers of 4000x3000 in 10.5 ms against 5.65 ms -- a lone wave needs ~1.3 us per row of
+// ~400 instructions, and with two register sets only three waves fit a SIMD).  It stays buildable and tested
+// (tests/test_gpu_kernels.py runs the optimise vectors through it) because its parts are the plan for the next step.
 bool ws_supported(int w, int h, int n_max, int n_min) {
-    static const bool off = getenv("MRCHIP_OPT_WS") && atoi(getenv("MRCHIP_OPT_WS")) == 0;
-    return !off && n_min >= 1 && n_max <= 11 && h < 65536 && w >= 1;
+    static const bool on = getenv("MRCHIP_OPT_WS") && atoi(getenv("MRCHIP_OPT_WS")) != 0;
+    // (n >= 2: the leaving output row of row y + 2 is requested while row y is being made; it is row y + 1 - n)
+    return on && n_min >= 2 && n_max <= 11 && h < 65536 && w >= 1;
 }
 
 // h_jobs: host copy (its ws_* fields are filled here), d_jobs: where it is uploaded to.  All jobs share w, h, c; every
@@ -689,7 +728,7 @@ int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d
         smax = std::max(smax, j.ws_S);
         if (j.n != 3 && j.n != 10) generic = true;
     }
-    const size_t need = granules * sizeof(u64);
+    const size_t need = granules * sizeof(u64) + 4096;     // (strips without a left neighbour still issue their hand-off loads)
     if (need > mail->bytes) {
         HIP_TRY(hipStreamSynchronize(s));
         TRY(mail->buf.alloc(ctx, need + need / 8));

@@ -178,6 +178,32 @@ def pmc_traffic(name, alg_per_launch):
         return None, None
 
 
+def valu_roofline(name, alg_per_launch, bytes_per_px):
+    """The instruction side of the roofline for kernel `name` from the committed SQ / GRBM counter passes
+    (profiles/*_valu_summary.json, written by tools/profile_round.sh beside the FETCH / WRITE passes): VALU
+    wave-instructions per 64 pixels (= lane-instructions per pixel), cycles per instruction, VALU-busy fraction."""
+    sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
+           'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_valu_summary.json')))[-1]
+        d = json.load(open(f))
+        sc = d.get('scale', {}).get(name, {})
+        for k, v in d['kernels'].items():
+            if sym in k and 'alg_bytes_per_launch' in sc:
+                px = sc['alg_bytes_per_launch'] / bytes_per_px
+                return {'insts_per_px': round(v['valu_wave_insts_per_launch'] / (px / 64.0), 2), 'busy_frac': v['busy_frac'],
+                        'cycles_per_inst': v['cycles_per_inst'],
+                        'what': 'VALU wave-instructions per 64 pixels; fraction of the launch a SIMD VALU was busy; issue '
+                                'cycles per instruction -- at ~4 cycles each and 1024 SIMDs x 2.4 GHz the chip issues 39 T '
+                                'lane-instructions/s, i.e. 0.6 of the byte roofline needs <= 16 per Sauvola pixel, <= 57 per '
+                                'optimise RGB pixel',
+                        'source': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
+        return None
+    except Exception:
+        return None
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: this process never touches the GPU, starts N fresh child processes
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; ordinary children, never os.exec*), relays rank 0's JSON line on its
@@ -462,9 +488,11 @@ def main():
         alg = r['alg_bytes'] / r['launches']
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic, src = pmc_traffic(name, alg)
+        bpp = {'optimise_rgb': 7.0, 'optimise_gray': 3.0, 'sauvola': 2.0, 'sauvola_boxes': 4.0}.get(name)
         return {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': src,
-                'avg_launch_ms': round(ms, 4), 'launches': r['launches'], 'alg_bytes_per_launch': alg}
+                'avg_launch_ms': round(ms, 4), 'launches': r['launches'], 'alg_bytes_per_launch': alg,
+                'valu': valu_roofline(name, alg, bpp) if bpp else None}
 
     # The dominant kernel: the one with the largest share of GPU time when kernels have the chip to themselves (the
     # isolated pass, when it ran).  With several batches in flight a launch's HIP-event duration includes the time it

@@ -241,3 +241,40 @@ def test_optimise_whole_rows_and_column_strips_agree_with_the_oracle(monkeypatch
                 monkeypatch.setenv('MRCHIP_OPT_STRIPS', mode)
             got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
             assert np.array_equal(got, exp), ((h, w, c, n, dens), mode, int((got != exp).sum()))
+
+
+WS_CHECK = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, 'archive-pdf-tools_amd')); sys.path.insert(0, os.path.join(%(root)r, 'oracle'))
+import mrc_oracle as O
+from mrchip import _lib, synth
+lib = _lib.load(); ctx = _lib.default_context()
+bad = []
+for (w, h, c, seed, ns) in [(450, 350, 3, 4, 12.0), (1000, 600, 3, 9, 6.0), (230, 300, 1, 1, 6.0), (777, 401, 1, 3, 2.0), (2500, 700, 3, 5, 6.0)]:
+    img, hocr = synth.synth_page(w, h, c, seed=seed, noise_sigma=ns, line_div=16)
+    mask = next(O.create_mrc_hocr_components(img, hocr, denoise_mask='fast')).astype(np.uint8)
+    for n, inv in ((3, 0), (10, 1), (5, 0), (7, 1), (2, 1)):
+        mi = (1 - mask) if inv else mask
+        exp = (O.optimise_rgb2 if c == 3 else O.optimise_gray2)(mi, img, w, h, n)
+        for rep in range(2):
+            got = np.empty_like(img)
+            _lib.check(lib.mrchip_optimise(ctx.handle, _lib.ptr(mask), _lib.ptr(img), _lib.ptr(got), w, h, c, n, inv))
+            if not np.array_equal(exp, got):
+                bad.append((w, h, c, n, inv, int((exp != got).sum())))
+print('WS_BAD', bad)
+'''
+
+
+def test_optimise_wave_strip_schedule_opt_in():
+    """k_optimise_ws.hip (MRCHIP_OPT_WS=1, not the default schedule): dense layers with dormant rows and wake-ups, sparse ones
+    with the short path, strips with hand-off, gray and RGB, n from 2 to 10 -- against the oracle, twice each (the hand-off
+    buffer's epoch)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRCHIP_OPT_WS='1')
+    r = subprocess.run([sys.executable, '-c', WS_CHECK % {'root': root}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'WS_BAD []' in r.stdout, r.stdout[-2000:]

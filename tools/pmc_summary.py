@@ -21,6 +21,36 @@ def short(name):
     return name.split('(')[0].replace('void ', '').strip()
 
 
+def valu_summary(src, tag, out, note, head, scale):
+    """<tag>_valu_summary.json: the instruction roofline per kernel from the SQ / GRBM passes of the same command --
+    VALU wave-instructions per launch, cycles the VALU was busy per instruction (SQ_ACTIVE_INST_VALU counts quad-cycles),
+    fraction of the launch during which a SIMD's VALU was busy (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for kind in ('valu', 'gui'):
+        path = os.path.join(src, 'pmc_' + kind, tag + '_counter_collection.csv')
+        if not os.path.exists(path):
+            return
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                k = short(r['Kernel_Name'])
+                agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+                cnt[(k, r['Counter_Name'])] += 1
+    kernels = {}
+    for k, v in agg.items():
+        a = {c: x / cnt[(k, c)] for c, x in v.items()}
+        insts, act, gui = a.get('SQ_INSTS_VALU', 0.0), a.get('SQ_ACTIVE_INST_VALU', 0.0), a.get('GRBM_GUI_ACTIVE', 0.0)
+        if insts <= 0 or gui <= 0:
+            continue
+        kernels[k] = {'launches': cnt[(k, 'SQ_INSTS_VALU')], 'valu_wave_insts_per_launch': round(insts),
+                      'valu_busy_quadcycles_per_launch': round(act), 'gui_active_cycles_per_launch_sum_xcd': round(gui),
+                      'cycles_per_inst': round(4.0 * act / insts, 3), 'busy_frac': round(act / (32.0 * gui), 4),
+                      'wave_cycles_per_launch': round(a.get('SQ_WAVE_CYCLES', 0.0))}
+    with open(os.path.join(out, tag + '_valu_summary.json'), 'w') as f:
+        json.dump({'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU | GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace -- python3 bench.py ' + note,
+                   'bench_args': note, 'head': head, 'scale': scale, 'kernels': kernels}, f, indent=1)
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     note = sys.argv[3] if len(sys.argv) > 3 else ''
@@ -75,6 +105,7 @@ def main():
     with open(os.path.join(out, tag + '_pmc_summary.json'), 'w') as f:
         json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py ' + note,
                    'bench_args': note, 'head': head, 'scale': scale, 'kernels': {r['kernel']: r for r in rows}}, f, indent=1)
+    valu_summary(src, tag, out, note, head, scale)
     for r in rows[:12]:
         print('%-45s n=%3d  read %.3f GB  write %.3f GB  avg %.3f ms' % (r['kernel'][:45], r['launches'],
               r['read_bytes_per_launch_gfx950_corrected'] / 1e9, r['write_bytes_per_launch'] / 1e9, r['avg_ns_kernel_trace'] / 1e6))
