@@ -659,6 +659,33 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
         placement['error'] = str(e)
     link = link_rates(ctx) if rank == 0 else None
     pool = mrc.StreamPool(ctx)        # device batches + page-locked result arrays made once, as a long-running caller would
+
+    def run_stream(page_iter_factory, timed_hook=None):
+        gen = mrc.decompose_stream(page_iter_factory(), dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
+                                   batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool)
+        for _ in gen:                   # first pass also allocates the slots: run the stream twice, time the second
+            pass
+        comm.barrier()
+        phases = {}
+        gen = mrc.decompose_stream(page_iter_factory(), dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
+                                   batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool, stats=phases)
+        t0 = time.perf_counter()
+        n = 0
+        out_bytes = 0
+        for m, fg, bg in gen:
+            n += 1
+            out_bytes = m.nbytes + fg.nbytes + bg.nbytes
+            if timed_hook:
+                timed_hook(n)
+        ctx.sync()
+        comm.barrier()
+        dt = comm.max_f64(time.perf_counter() - t0)
+        in_bytes = W * H * Cc
+        return {'pages_per_s': round(n * world / dt, 1), 'h2d_GBps_per_gpu': round(n * in_bytes / dt / 1e9, 1),
+                'd2h_GBps_per_gpu': round(n * out_bytes / dt / 1e9, 1), 'seconds': round(dt, 3),
+                'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}, out_bytes
+
+    out_bytes = 0
     for mode in ('pageable', 'pinned'):
         if mode == 'pinned':       # the page source decodes into page-locked arrays: uploads are asynchronous DMAs
             src = []
@@ -668,31 +695,73 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
                 src.append((p, hocr))
         else:
             src = [(img, hocr) for img, hocr, _ in host_pages]
-        gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
-                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool)
-        warm = 0
-        for _ in gen:                   # first pass also allocates the slots: run the stream twice, time the second
-            warm += 1
-        comm.barrier()
-        phases = {}
-        gen = mrc.decompose_stream(((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)), dpi=cfg['dpi'],
-                                   bg_downsample=cfg['bg'], fg_downsample=cfg['fg'], batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool,
-                                   stats=phases)
-        t0 = time.perf_counter()
-        n = 0
-        out_bytes = 0
-        for m, fg, bg in gen:
-            n += 1
-            out_bytes = m.nbytes + fg.nbytes + bg.nbytes
-        ctx.sync()
-        comm.barrier()
-        dt = comm.max_f64(time.perf_counter() - t0)
-        in_bytes = W * H * Cc
-        res[mode] = {'pages_per_s': round(n * world / dt, 1), 'h2d_GBps_per_gpu': round(n * in_bytes / dt / 1e9, 1),
-                     'd2h_GBps_per_gpu': round(n * out_bytes / dt / 1e9, 1), 'seconds': round(dt, 3),
-                     'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}
+        res[mode], out_bytes = run_stream(lambda: ((src[i % len(src)][0], src[i % len(src)][1]) for i in range(n_pages)))
+        res[mode]['source'] = '%d host arrays recycled over %d pages (the HIP runtime has seen every buffer before)' % (len(src), n_pages)
+
+    # ---- what a page loop that DECODES pages gets (recode.py:343-348): every page in a host buffer the runtime has never
+    # seen.  (a) n_pages distinct pageable arrays handed to the stream as they are; (b) the same arrays copied by a
+    # producer thread into a ring of page-locked buffers ahead of the stream.  Both passes of a run use
+    # their own fresh arrays; bounded by the host memory that is free.
+    page_bytes = W * H * Cc
+    n_fresh = n_pages
+    try:
+        import psutil
+        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, psutil.virtual_memory().available * 0.25 // (2 * page_bytes))))
+    except Exception:      # noqa: BLE001
+        n_fresh = min(n_pages, 128)
+    if os.environ.get('MRCHIP_BENCH_FRESH', '1') != '0':
+        def fresh_arrays():
+            return [np.array(host_pages[i % nd][0], copy=True) for i in range(n_fresh)]       # new allocations, never uploaded
+        passes = [fresh_arrays(), fresh_arrays()]
+        it = iter(passes)
+
+        def fresh_factory():
+            arrs = next(it)
+            return ((arrs[i], host_pages[i % nd][1]) for i in range(n_fresh))
+        res['fresh_pageable'], out_bytes = run_stream(fresh_factory)
+        res['fresh_pageable']['source'] = '%d distinct pageable arrays, each uploaded once' % n_fresh
+        del passes
+
+        import threading
+        RING = E2E_BATCH * (E2E_SLOTS + 4)
+        ring = [ctx.pinned_empty(host_pages[0][0].shape) for _ in range(RING)]
+        state = {}
+
+        def ring_factory():
+            arrs = fresh_arrays()
+            filled = threading.Semaphore(0)
+            st = {'taken': 0, 'lock': threading.Condition()}
+            state['st'] = st
+
+            def producer():
+                for i in range(n_fresh):
+                    with st['lock']:            # a slot is rewritten only when the page that used it has been handed out
+                        while i >= st['taken'] + RING - E2E_BATCH:
+                            st['lock'].wait(0.05)
+                    np.copyto(ring[i % RING], arrs[i])          # releases the GIL: runs beside the stream's thread
+                    filled.release()
+            th = threading.Thread(target=producer, daemon=True)
+            th.start()
+
+            def pages():
+                for i in range(n_fresh):
+                    filled.acquire()
+                    yield ring[i % RING], host_pages[i % nd][1]
+            return pages()
+
+        def took(n):
+            st = state['st']
+            with st['lock']:
+                st['taken'] = n
+                st['lock'].notify_all()
+        res['pinned_ring'], out_bytes = run_stream_ring(mrc, ctx, comm, cfg, pool, ring_factory, took, world, W * H * Cc)
+        res['pinned_ring']['source'] = ('%d distinct pageable arrays copied by a producer thread into a ring of %d page-locked '
+                                        'buffers ahead of the stream' % (n_fresh, RING))
+        del ring
     pool.close()
-    best = max(res.values(), key=lambda r: r['pages_per_s'])
+    # the headline of this leg: pages in buffers the runtime has not seen (the recycled-array figures are upper bounds)
+    fresh = [res[k] for k in ('fresh_pageable', 'pinned_ring') if k in res]
+    best = max(fresh or list(res.values()), key=lambda r: r['pages_per_s'])
     out = {'pages_per_s': best['pages_per_s'], 'pages_per_gpu': n_pages, 'batch_pages': E2E_BATCH, 'slots': E2E_SLOTS,
            'host_placement': placement,
            'host_arrays': res, 'bytes_in_per_page': W * H * Cc, 'bytes_out_per_page': out_bytes,
@@ -709,6 +778,32 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
             out['duplex_ceiling_pages_per_s_per_gpu'] = round(dlim, 1)      # ... at the rate both reach when they run at once
             out['frac_of_duplex_ceiling'] = round(best['pages_per_s'] / world / dlim, 3)
     return out
+
+
+def run_stream_ring(mrc, ctx, comm, cfg, pool, factory, took, world, in_bytes):
+    """the pinned-ring variant of e2e_stream's timed loop: both passes report the pages handed out to the producer"""
+    out_bytes = 0
+    res = None
+    for timed in (False, True):
+        phases = {}
+        gen = mrc.decompose_stream(factory(), dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
+                                   batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool, stats=phases)
+        if timed:
+            comm.barrier()
+        t0 = time.perf_counter()
+        n = 0
+        for m, fg, bg in gen:
+            n += 1
+            out_bytes = m.nbytes + fg.nbytes + bg.nbytes
+            took(n)
+        ctx.sync()
+        if timed:
+            comm.barrier()
+            dt = comm.max_f64(time.perf_counter() - t0)
+            res = {'pages_per_s': round(n * world / dt, 1), 'h2d_GBps_per_gpu': round(n * in_bytes / dt / 1e9, 1),
+                   'd2h_GBps_per_gpu': round(n * out_bytes / dt / 1e9, 1), 'seconds': round(dt, 3),
+                   'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}
+    return res, out_bytes
 
 
 def stack_check(ctx, comm, mrc, synth, cfg, rank, world):
