@@ -1102,8 +1102,15 @@ __global__ __launch_bounds__(MAXT) void optimise_strip_kernel(const OptJob *jobs
     const OptJob J = jobs[job];
     // strips of up to 512 threads: the double-buffered LDS rows (one barrier per row) always fit; 1024 threads: single rows
     constexpr bool DB = MAXT <= 512;
-    if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true, true>(J, smem, SI, job, strip);
-    else optimise_packed_rows<C, 2, 10, DB, true, true>(J, smem, SI, job, strip);
+    if (J.mbits) {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, DB, true, true>(J, smem, SI, job, strip);
+    } else {
+        if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, false, true>(J, smem, SI, job, strip);
+        else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, false, true>(J, smem, SI, job, strip);
+        else optimise_packed_rows<C, NH, -1, DB, false, true>(J, smem, SI, job, strip);
+    }
 }
 
 // Self-test of the quotient both optimise kernels use: (unsigned)fma((float)v, rcp(cnt), rcp(cnt)/2) against

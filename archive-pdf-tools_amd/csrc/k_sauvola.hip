@@ -598,7 +598,9 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     for (int i = 0; i < njobs; i++) want_bits = want_bits || h_jobs[i].bits != nullptr;
     if (want_bits) {
         if (K < 8) { set_error("sauvola: 1-bpp output needs the 8- or 16-column kernel (sauvola_writes_bits)"); return MRCHIP_E_ARG; }
-        P.two &= ~7;          // strips start at whole bytes of the bit rows
+        // strips start at whole stores of the bit rows: a byte per lane for K = 8, a 16-bit short per lane for K = 16 (with
+        // 8-column alignment two strips of the K = 16 kernel would share a short and race on it)
+        P.two &= ~(K - 1);
     }
     if (P.two < 4) {
         set_error("sauvola: window width %d too large for the %d-column strip", P.ww, CW);

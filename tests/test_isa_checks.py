@@ -1,0 +1,55 @@
+"""Listing checks that need no GPU: hipcc cross-compiles the two kernels with hand-counted asynchronous loads to
+assembly, tools/isa_inflight.py scans them for reads of a register between the asm load that targets it and the asm
+`s_waitcnt vmcnt(N)` covering it ("the torn copy"), and the listing must show no spills in those kernels
+(a spill of an in-flight register stores stale data)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'archive-pdf-tools_amd', 'csrc')
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+def _listing(tmp_path, name):
+    if not os.path.exists(HIPCC):
+        pytest.skip('no hipcc')
+    out = str(tmp_path / (name + '.s'))
+    r = subprocess.run([HIPCC, '-std=c++17', '-O3', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-S',
+                        '--cuda-device-only', os.path.join(CSRC, name + '.hip'), '-o', out], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def _scan(listing, key):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_inflight.py'), listing, key], capture_output=True, text=True)
+    return r.returncode, r.stdout
+
+
+def _scratch_of(listing, key):
+    txt = open(listing).read()
+    m = re.search(r'\.amdhsa_kernel (\S*%s\S*)(.*?)\.end_amdhsa_kernel' % re.escape(key), txt, re.S)
+    assert m, key
+    return int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', m.group(2)).group(1))
+
+
+def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
+    lst = _listing(tmp_path, 'k_sauvola')
+    for key in ('sauvola_kernelILi8ELb1ELb1ELb0', 'sauvola_kernelILi4ELb1ELb1ELb1', 'sauvola_kernelILi8ELb0ELb0ELb0',
+                'sauvola_kernelILi16ELb1ELb0ELb0'):
+        rc, out = _scan(lst, key)
+        assert rc == 0, (key, out[-1500:])
+        assert _scratch_of(lst, key) == 0, key
+
+
+def test_wave_strip_requests_are_never_read_in_flight(tmp_path):
+    lst = _listing(tmp_path, 'k_optimise_ws')
+    key = 'optimise_ws_kernelILi3ELi0E'                 # RGB, the reference's two call sites
+    rc, out = _scan(lst, key)
+    assert rc == 0, out[-1500:]
+    assert _scratch_of(lst, key) == 0
