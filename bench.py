@@ -159,20 +159,31 @@ def git_head():
         return None
 
 
+# kernel symbol (as rocprofv3 prints it) behind a profile name; the page and the hOCR-box launches of Sauvola are two
+# instances of one template (the 4th argument: both polarities)
+KERNEL_SYMBOL = {'optimise_rgb': r'optimise_packed_kernel<3', 'optimise_gray': r'optimise_packed_kernel<1',
+                 'sauvola': r'sauvola_kernel<\d+, \w+, \w+, false', 'sauvola_boxes': r'sauvola_kernel<\d+, \w+, \w+, true'}
+
+
+def _profile_kernel(kernels, name):
+    import re
+    pat = re.compile(KERNEL_SYMBOL.get(name, re.escape(name)))
+    hits = [(k, v) for k, v in kernels.items() if pat.search(k)]
+    return max(hits, key=lambda kv: kv[1].get('launches', 0))[1] if hits else None
+
+
 def pmc_traffic(name, alg_per_launch):
     """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
     2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size -- with the provenance, so a
     stale profile cannot pass for a measurement of this build."""
-    sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
-           'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
     try:
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
         d = json.load(open(f))
         src = {'file': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
-        for k, v in d['kernels'].items():
-            if sym in k and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
-                return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch']), src
+        v = _profile_kernel(d['kernels'], name)
+        if v and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
+            return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch']), src
         return None, src
     except Exception:
         return None, None
@@ -182,15 +193,14 @@ def valu_roofline(name, alg_per_launch, bytes_per_px):
     """The instruction side of the roofline for kernel `name` from the committed SQ / GRBM counter passes
     (profiles/*_valu_summary.json, written by tools/profile_round.sh beside the FETCH / WRITE passes): VALU
     wave-instructions per 64 pixels (= lane-instructions per pixel), cycles per instruction, VALU-busy fraction."""
-    sym = {'optimise_rgb': 'optimise_packed_kernel<3', 'optimise_gray': 'optimise_packed_kernel<1',
-           'sauvola': 'sauvola_kernel', 'sauvola_boxes': 'sauvola_kernel'}.get(name, name)
     try:
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_valu_summary.json')))[-1]
         d = json.load(open(f))
         sc = d.get('scale', {}).get(name, {})
-        for k, v in d['kernels'].items():
-            if sym in k and 'alg_bytes_per_launch' in sc:
+        v = _profile_kernel(d['kernels'], name)
+        if True:
+            if v and 'alg_bytes_per_launch' in sc:
                 px = sc['alg_bytes_per_launch'] / bytes_per_px
                 return {'insts_per_px': round(v['valu_wave_insts_per_launch'] / (px / 64.0), 2), 'busy_frac': v['busy_frac'],
                         'cycles_per_inst': v['cycles_per_inst'],
@@ -427,11 +437,13 @@ def main():
                                           '(tests/golden/configs.json)'}
             if a.config == 'c5':
                 try:
-                    d5 = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')))['c5']
-                    r0 = [r for r in allrecs if r['seed'] == 505]
-                    extra['parity'] = {'pages_checked': len(r0), 'mismatches': sum(1 for r in r0 if (r['mask'], r['fg'], r['bg']) !=
-                                                                                 (d5['mask'], d5['fg'], d5['bg'])),
-                                       'against': 'tests/golden/digests.json c5 (reference)'}
+                    dg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')))
+                    d5 = {505: dg['c5'], 506: dg['c5_506']}          # both distinct pages of the batch have reference digests
+                    r0 = [r for r in allrecs if r['seed'] in d5]
+                    extra['parity'] = {'pages_checked': len(r0),
+                                       'mismatches': sum(1 for r in r0 if (r['mask'], r['fg'], r['bg']) !=
+                                                         (d5[r['seed']]['mask'], d5[r['seed']]['fg'], d5[r['seed']]['bg'])),
+                                       'against': 'tests/golden/digests.json c5 / c5_506 (reference)'}
                 except Exception as e:     # pragma: no cover
                     extra['parity'] = {'error': str(e)}
 
@@ -724,28 +736,30 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
 
         import threading
         RING = E2E_BATCH * (E2E_SLOTS + 4)
+        RING_THREADS = 6
         ring = [ctx.pinned_empty(host_pages[0][0].shape) for _ in range(RING)]
         state = {}
 
         def ring_factory():
             arrs = fresh_arrays()
-            filled = threading.Semaphore(0)
             st = {'taken': 0, 'lock': threading.Condition()}
             state['st'] = st
 
-            def producer():
-                for i in range(n_fresh):
+            ready = [threading.Event() for _ in range(n_fresh)]
+
+            def producer(k):                    # RING_THREADS threads, page i by thread i mod RING_THREADS: one thread
+                for i in range(k, n_fresh, RING_THREADS):       # copies ~15 GB/s, a page is 36 MB
                     with st['lock']:            # a slot is rewritten only when the page that used it has been handed out
                         while i >= st['taken'] + RING - E2E_BATCH:
                             st['lock'].wait(0.05)
                     np.copyto(ring[i % RING], arrs[i])          # releases the GIL: runs beside the stream's thread
-                    filled.release()
-            th = threading.Thread(target=producer, daemon=True)
-            th.start()
+                    ready[i].set()
+            for k in range(RING_THREADS):
+                threading.Thread(target=producer, args=(k,), daemon=True).start()
 
             def pages():
                 for i in range(n_fresh):
-                    filled.acquire()
+                    ready[i].wait()
                     yield ring[i % RING], host_pages[i % nd][1]
             return pages()
 
@@ -756,7 +770,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
                 st['lock'].notify_all()
         res['pinned_ring'], out_bytes = run_stream_ring(mrc, ctx, comm, cfg, pool, ring_factory, took, world, W * H * Cc)
         res['pinned_ring']['source'] = ('%d distinct pageable arrays copied by a producer thread into a ring of %d page-locked '
-                                        'buffers ahead of the stream' % (n_fresh, RING))
+                                        'buffers ahead of the stream (%d copy threads)' % (n_fresh, RING, RING_THREADS))
         del ring
     pool.close()
     # the headline of this leg: pages in buffers the runtime has not seen (the recycled-array figures are upper bounds)
