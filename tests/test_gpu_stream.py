@@ -103,3 +103,25 @@ def test_one_batch_object_serves_growing_page_counts():
             assert np.array_equal(bt.download_mask(j), em)
             assert np.array_equal(bt.download_layer(j, 0, fgs), ef) and np.array_equal(bt.download_layer(j, 1, bgs), eb)
     bt.close()
+
+
+def test_book_of_many_page_sizes_stays_inside_the_pool_budget():
+    """one idle 8-page slot per distinct geometry does not scale to scanned books whose pages all differ in size.
+    Slots are sized to the run they serve and idle slots of other sizes are closed under a byte budget -- results unchanged."""
+    pages = [synth.synth_page(300 + 7 * i, 220 + 3 * (i % 5), 3 if i % 3 else 1, seed=500 + i, noise_sigma=5.0, line_div=10)
+             for i in range(24)]
+    pages += [pages[3]] * 5                                 # and a run of equal pages at the end
+    budget = 6 * mrc._slot_bytes(1, 480, 240, 3)
+    with mrc.StreamPool(max_bytes=budget) as pool:
+        peak = 0
+        got = []
+        for res in mrc.decompose_stream(iter(pages), bg_downsample=2, batch_pages=4, copy=True, pool=pool):
+            got.append(res)
+            peak = max(peak, pool.bytes_held())
+        assert len(got) == len(pages)
+        # four slots are in flight at any time (they cannot be closed); nothing beyond them piles up
+        assert len(pool.every) <= 8 and peak <= budget + 4 * mrc._slot_bytes(4, 480, 240, 3), (len(pool.every), peak, budget)
+        assert all(sl.key[0] <= 4 for sl in pool.every)
+    for (img, hocr), (m, fg, bg) in zip(pages, got):
+        em, ef, eb = _expect(img, hocr, bg_downsample=2)
+        assert np.array_equal(m, em) and np.array_equal(fg, ef) and np.array_equal(bg, eb)
