@@ -718,21 +718,23 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     n_fresh = n_pages
     try:
         import psutil
-        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, psutil.virtual_memory().available * 0.25 // (2 * page_bytes))))
+        # one pass of distinct arrays is alive at a time on every rank of the node: a quarter of the free memory between them
+        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, psutil.virtual_memory().available * 0.25 // (max(world, 1) * page_bytes))))
     except Exception:      # noqa: BLE001
         n_fresh = min(n_pages, 128)
     if os.environ.get('MRCHIP_BENCH_FRESH', '1') != '0':
         def fresh_arrays():
             return [np.array(host_pages[i % nd][0], copy=True) for i in range(n_fresh)]       # new allocations, never uploaded
-        passes = [fresh_arrays(), fresh_arrays()]
-        it = iter(passes)
+        def fresh_factory():                # each pass of run_stream (warm, timed) gets arrays of its own, freed as it goes
+            arrs = fresh_arrays()
 
-        def fresh_factory():
-            arrs = next(it)
-            return ((arrs[i], host_pages[i % nd][1]) for i in range(n_fresh))
+            def pages():
+                for i in range(n_fresh):
+                    a, arrs[i] = arrs[i], None
+                    yield a, host_pages[i % nd][1]
+            return pages()
         res['fresh_pageable'], out_bytes = run_stream(fresh_factory)
         res['fresh_pageable']['source'] = '%d distinct pageable arrays, each uploaded once' % n_fresh
-        del passes
 
         import threading
         RING = E2E_BATCH * (E2E_SLOTS + 4)
