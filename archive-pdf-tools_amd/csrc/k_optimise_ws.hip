@@ -346,7 +346,10 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
     };
     In SA, SB;
     auto request_top = [&](In &S, int ys) {            // inputs of row ys but its current image row
-        const int ye = min(max(ys + n - 1, 0), h - 1), yl = min(max(ys - n - 1, 0), h - 1), yg = min(max(ys - 1, 0), h - 1);
+        const int ye = min(max(ys + n - 1, 0), h - 1), yl = min(max(ys - n - 1, 0), h - 1);
+        // (a strip without a left neighbour asks for row 0 of the job's first boundary every time: its part of the buffer
+        // holds at least one row of units even when the job has a single strip)
+        const int yg = strip > 0 ? min(max(ys - 1, 0), h - 1) : 0;
         asm volatile("global_load_dword %0, %1, %2" : "=v"(S.mw) : "v"(vo_m), "s"((const uint8_t *)(mbits + (size_t)ye * mwpr)) : "memory");
         px_load_async<C>(S.e, vo_px, img + (size_t)ye * ipitch);
         px_load_async<C>(S.lv, vo_px, img + (size_t)yl * ipitch);
@@ -724,7 +727,7 @@ int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d
         OptJob &j = h_jobs[i];
         ws_geometry(w, j.n, &j.ws_S, &j.ws_clb);
         j.ws_mail = granules;
-        granules += (size_t)std::max(j.ws_S - 1, 0) * h * ((j.n + 3) >> 2) * c;
+        granules += std::max((size_t)std::max(j.ws_S - 1, 0) * h, (size_t)1) * ((j.n + 3) >> 2) * c;
         smax = std::max(smax, j.ws_S);
         if (j.n != 3 && j.n != 10) generic = true;
     }
