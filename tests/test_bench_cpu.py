@@ -19,7 +19,7 @@ def test_traffic_of_both_roofline_kernels_comes_from_the_committed_profile():
 
 def test_committed_bench_lines_have_the_contract_fields():
     for cfg in ('c2', 'c3', 'c3gray', 'c5'):
-        with open(os.path.join(ROOT, 'profiles', 'r02_bench_%s.json' % cfg)) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_bench_%s.json' % cfg)) as f:
             d = json.load(f)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                     'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
@@ -28,11 +28,20 @@ def test_committed_bench_lines_have_the_contract_fields():
         r = d['roofline']
         assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4
         assert d['parity']['mismatches'] == 0
-    with open(os.path.join(ROOT, 'profiles', 'r02_bench_c2.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r03_bench_c2.json')) as f:
         c2 = json.load(f)
     assert c2['cpu_baseline']['kind'] == 'port' and c2['cpu_baseline']['cores'] >= 1
     assert c2['roofline']['kernel'] == 'optimise_rgb'            # ranked in the isolated pass, not by overlapped HIP events
     assert c2['config4_stack']['mismatches'] == 0 and c2['config4_stack']['all_pages_present']
+    # round 3: the instruction side of the roofline, the control plane's status, page sources the runtime has never seen
+    v = c2['roofline']['valu']
+    assert v['source'].startswith('profiles/') and 30 < v['insts_per_px'] < 60 and 0.3 < v['busy_frac'] <= 1.0
+    assert 3.5 < v['cycles_per_inst'] < 5.0 and 35 < c2['sauvola_roofline']['valu']['insts_per_px'] < 60
+    assert c2['rccl_ok'] is True and c2['rccl_ranks'] == 1 and c2['n_gpus'] == 1
+    assert {'fresh_pageable', 'pinned_ring'} <= set(c2['e2e']['host_arrays'])
+    assert c2['e2e']['pages_per_s'] == max(c2['e2e']['host_arrays'][k]['pages_per_s'] for k in ('fresh_pageable', 'pinned_ring'))
+    with open(os.path.join(ROOT, 'profiles', 'r03_bench_c5.json')) as f:
+        assert json.load(f)['parity']['pages_checked'] == 2                     # both 8000x6000 pages have reference digests
 
 
 def test_build_stamp_and_stream_defaults():
