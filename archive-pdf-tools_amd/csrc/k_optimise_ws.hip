@@ -1,27 +1,27 @@
 // optimise_gray2 / optimise_rgb2 (reference: cython/optimiser.pyx:153-273, 280-429) for gfx950 -- the wave-strip
-// schedule.  Semantics and arithmetic as in k_optimise.hip (same packed 16-bit column sums, same exact quotient); what
-// differs is who walks the rows.
+// schedule.  OPT-IN (MRCHIP_OPT_WS=1): bit-exact and tested, but slower than the workgroup schedule of k_optimise.hip
+// on MI355X (DESIGN.md 5.R3 has the measurements and the reasons).  Semantics and arithmetic as in k_optimise.hip (same
+// packed 16-bit column sums, same exact quotient); what differs is who walks the rows.
 //
 // The causal window of optimise looks LEFT and UP only: pixel (y, x) needs outputs of rows y-n .. y-1, columns
 // x-n .. x-1, never of its own row (pyx:213-220, 250-255).  So a page-layer is cut into column strips of ONE WAVE each
 // (<= 62 lanes x 4 columns of core, plus halo lanes on both sides), every wave walks its strip top to bottom at its own
 // pace, and the only thing that crosses a strip boundary is, per finished row, the n output columns at the boundary:
-// one 16-byte granule per 4 columns {12 bytes of output, tag}, written write-through (`sc0 sc1`) by the left strip's
-// last lanes and read `sc0 sc1` by the right strip's left-halo lanes (MI355X_MICROARCH.md, inter-workgroup
-// visibility: a data-tagged granule needs no fence and no flag, wherever the two waves run).  There is no workgroup
-// barrier anywhere: a wave that waits (for memory, for its neighbour) leaves the SIMD to the other waves resident
-// there, which belong to other strips, other page-layers, fg (n = 3) and bg (n = 10) alike -- the whole launch is one
-// pool of independent waves, and the chip is full as long as there are more strips than wave slots.
-// Whole rows on one 1024-thread workgroup (k_optimise.hip) spent a third of the time in the per-row chain
-// publish -> barrier -> window reads with the VALU idle (round 2: 64 % busy).
+// per 4 columns three (RGB) / one (gray) 8-byte units {dword of output bytes, tag}, written and read by relaxed
+// system-scope atomics (write-through `sc0 sc1`; MI355X_MICROARCH.md, inter-workgroup visibility: a data-tagged unit
+// needs no fence and no flag, wherever the two waves run).  There is no workgroup barrier anywhere.
 //
 //  * halo: lanes left of the core rebuild the vertical FIR sums of the neighbour's last columns from the inputs and get
-//    the vertical IIR sums of those columns from the granules; lanes right of the core need FIR sums only.
+//    the vertical IIR sums of those columns from the hand-off units (kept n + 1 rows deep in an LDS ring: a row is needed
+//    again when it leaves the sums); lanes right of the core need FIR sums only.
 //    HL = ceil(n / 4) lanes on the left, HR = ceil((n - 1) / 4) on the right.
 //  * the horizontal windows slide over two wave-private LDS rows (entries of the 256 columns of the wave): LDS
 //    operations of one wave execute in order, so there is no wait between publish and window reads either.
 //  * the 1-bpp mask is loaded ONCE per row (the entering row); the lane's nibble goes into a shift register of
 //    2n + 1 nibbles from which the current and the leaving row's selection come out again.
+//  * a row's inputs are requested two rows ahead into one of two register sets by hand-counted asm loads (ws_rows).
+//  * rows without "rare" pixels in the window are cheap: a dense layer goes dormant (copies rows, rebuilds its sums from
+//    the image when needed), a sparse one takes a short path (ws_rows).
 //  * dispatch order = (page-layer, strip), left strips first: a consumer is never resident without its producer
 //    having been dispatched, so the polls always end; they are bounded all the same and a timeout is reported
 //    (OptMail error word, checked by the host at the next synchronisation point).
@@ -37,7 +37,6 @@ namespace mrchip {
 typedef const unsigned __attribute__((address_space(1))) *gc_u32p;
 typedef unsigned __attribute__((address_space(1))) *g_u32p;
 typedef uint8_t __attribute__((address_space(1))) *g_u8p;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned long long u64;
 
@@ -438,7 +437,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
         const unsigned nib_e = (y + n - 1 < h) ? nib_of_word(mw) : 0u;
         const bool rare_e = (y + n - 1 < h) && rare_any(nib_e);
         bool copyrow = false;
-#ifndef MRCHIP_WS_NODORMANT
         copyrow = !sparse && rare_rows == 0 && !rare_e;
         if (copyrow) dormant = true;          // DORMANT row: no unselected pixel in rows [y-n, y+n) of this wave's columns -> out = img
         else if (dormant) {
@@ -473,7 +471,6 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             for (int k = 2 * n; k >= 0; k--) { const int r = y + n - 2 - k; hist_push((r >= 0 && r < h) ? coln : 0u); }
             set_kf(y);
         }
-#endif
         unsigned nib_c = 0;
         bool shortrow = false;
         if (!copyrow) {
@@ -491,9 +488,7 @@ __device__ __forceinline__ void ws_rows(const OptJob &J, unsigned *lds, const Ws
             if (rare_e) rare_rows++;
             if (y - n - 1 >= 0 && rare_any(nib_l)) rare_rows--;
             // sparse layer, no selected pixel in rows [y-n, y+n): the short path (needs neither FIR sums nor the image row)
-#ifndef MRCHIP_WS_NOSHORT
             shortrow = SUMROW && sparse && rare_rows == 0;
-#endif
             // ---- vertical running sums for row y (wave-uniform row tests) ----
             if (y + n - 1 < h && n >= 1) fir_apply(e_px, nib_e, true);        // ye = min(h, y+n)
             if (y - n - 1 >= 0 && n >= 1) {
