@@ -412,6 +412,12 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     // n <= 7: FIR + IIR sums of a column (and of a whole window) fit the 16-bit lanes together, so the second LDS row
     // carries FIR + IIR entries and ONE accumulator slides over the row: T(x+1) = T(x) + fir[x+n] + iir[x] - (fir+iir)[x-n]
     constexpr bool SUMROW = (NH == 1 && NCT >= 0 && NCT <= 7);
+    // block sums in the pad slots: the window spans [x0-NCT, x0+NCT) = 2 + 4 + 4 | 4 + 4 + 2 columns for NCT = 10
+#ifdef MRCHIP_OPT_NO_BLOCKSUM
+    constexpr bool BLOCKSUM = false;
+#else
+    constexpr bool BLOCKSUM = (NH == 2 && NCT == 10);
+#endif
     const uint8_t *__restrict__ mask = J.mask;
     const uint8_t *__restrict__ img = J.img;
     uint8_t *out = J.out;
@@ -445,6 +451,9 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     // thread's base, the rest folds to an immediate when n is a compile-time constant.
     const int ebase = 5 * t * EW;
     auto eidx = [&](int col) { const int d = col - x0 + npad; return ebase + (d + (d >> 2)) * EW; };
+    // the pad slot inside the thread's own column group (after the own entry d with d % 4 == 3)
+    constexpr int DPAD = NCT >= 0 ? NCT + ((3 - NCT) & 3) : 0;
+    const int epad = ebase + (DPAD + (DPAD >> 2) + 1) * EW;
 
     const bool act = STRIP ? (x0 >= XS && x0 < XE) : (x0 < w);      // thread owns output columns
     const bool lhalo = STRIP && strip > 0 && x0 < XS && x0 >= XS - STRIP_HALO;     // carries the neighbour's IIR columns
@@ -697,6 +706,23 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
                 iirA[e] = second.d[0];
             }
         }
+        // n = 10 (two half-window accumulators): each thread also leaves the SUM of its four entries in the pad slot that lies
+        // inside its column group, so that a window starts from 4 block sums + 4 entries instead of 30 entries
+        // (4 columns x 20 rows x 255 = 20 400 per 16-bit lane)
+        Ent blkF, blkI;
+        if constexpr (BLOCKSUM) {
+            blkF = firE[0]; eadd(blkF, firE[1]); eadd(blkF, firE[2]); eadd(blkF, firE[3]);
+            blkI = iirE[0]; eadd(blkI, iirE[1]); eadd(blkI, iirE[2]); eadd(blkI, iirE[3]);
+            if (STRIP || x0 < wr) {
+                if constexpr (EW == 2) {
+                    *reinterpret_cast<uint2 *>(firA + epad) = make_uint2(blkF.d[0], blkF.d[1]);
+                    *reinterpret_cast<uint2 *>(iirA + epad) = make_uint2(blkI.d[0], blkI.d[1]);
+                } else {
+                    firA[epad] = blkF.d[0];
+                    iirA[epad] = blkI.d[0];
+                }
+            }
+        }
         lds_barrier();
 
         // Only pixels with mask==0 get a quotient.  When every pixel of this wave's 256 columns is masked
@@ -716,6 +742,19 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             for (int j = -NCT; j < 0; j++) eadd(aL, lds_ld(iirA, x0 + j));          // (fir + iir)[x0 + j]
 #pragma unroll
             for (int j = 0; j < NCT; j++) eadd(aL, j < P ? firE[j < P ? j : 0] : lds_ld(firA, x0 + j));
+        } else if constexpr (BLOCKSUM) {
+            // columns [x0-10, x0): two entries + the block sums of the two threads to the left; [x0, x0+10): the own block
+            // (registers), the right-hand neighbour's, two entries
+            auto pad_ld = [&](const unsigned *A, int k) {          // block sum of thread t + k
+                Ent e;
+                const unsigned *p = A + epad + 5 * k * EW;
+                if constexpr (EW == 2) { uint2 v = *reinterpret_cast<const uint2 *>(p); e.d[0] = v.x; e.d[1] = v.y; }
+                else e.d[0] = p[0];
+                return e;
+            };
+            aL = lds_ld(firA, x0 - NCT); eadd(aL, lds_ld(firA, x0 - NCT + 1)); eadd(aL, pad_ld(firA, -2)); eadd(aL, pad_ld(firA, -1));
+            aI = lds_ld(iirA, x0 - NCT); eadd(aI, lds_ld(iirA, x0 - NCT + 1)); eadd(aI, pad_ld(iirA, -2)); eadd(aI, pad_ld(iirA, -1));
+            aR = blkF; eadd(aR, pad_ld(firA, 1)); eadd(aR, lds_ld(firA, x0 + NCT - 2)); eadd(aR, lds_ld(firA, x0 + NCT - 1));
         } else if constexpr (NCT >= 0) {
 #pragma unroll
             for (int j = -NCT; j < 0; j++) { eadd(aL, lds_ld(firA, x0 + j)); eadd(aI, lds_ld(iirA, x0 + j)); }
