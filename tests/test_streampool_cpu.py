@@ -76,3 +76,42 @@ def test_eviction_prefers_other_geometries_and_least_recently_used(monkeypatch):
         pool.give(s)
     pool.close()
     assert _Slot.live == 0
+
+
+def test_stage_clock_books_gpu_time_per_key_and_the_rest_on_the_phase_key():
+    """timing_data (mrc.py:363-468): every key = the GPU time of its kernels (differences of the profile's running totals),
+    the phase's remainder on the key that stands for the phase, a caller's profiling session left as it was."""
+    from mrchip import mrc
+
+    class Ctx:
+        def __init__(self, on):
+            self.prof_on = on
+            self.calls = []
+            self.t = {'luma601': 1.0, 'sauvola_boxes': 2.0, 'hocr_commit': 0.5, 'dwt_dd_f32': 0.25, 'optimise_rgb': 8.0}
+
+        def prof_enable(self, on):
+            self.calls.append(on)
+            self.prof_on = on
+
+        def prof_report(self):
+            return {k: {'ms': v, 'launches': 1, 'alg_bytes': 0.0} for k, v in self.t.items()}
+
+    ctx = Ctx(False)
+    clock = mrc._StageClock(ctx, True)
+    assert ctx.calls == [True]
+    ctx.t['luma601'] += 2.0; ctx.t['sauvola_boxes'] += 3.0; ctx.t['dwt_dd_f32'] += 1.0; ctx.t['median_hist'] = 0.5
+    g = clock.lap()
+    assert abs(g['grey_conversion'] - 0.002) < 1e-12 and abs(g['hocr_mask_gen'] - 0.003) < 1e-12 and abs(g['est_1'] - 0.0015) < 1e-12
+    td = []
+    mrc._book(td, 0.010, 'hocr_mask_gen', [('grey_conversion', g['grey_conversion']), ('hocr_mask_gen', g['hocr_mask_gen']),
+                                           ('est_1', g['est_1'])])
+    assert [k for k, _ in td] == ['grey_conversion', 'hocr_mask_gen', 'est_1']
+    assert abs(sum(v for _, v in td) - 0.010) < 1e-12 and abs(dict(td)['hocr_mask_gen'] - (0.003 + 0.0035)) < 1e-12
+    assert clock.lap()['partial_blur'] == 0.0                      # nothing ran since the last lap
+    clock.close()
+    assert ctx.calls == [True, False]
+    ctx2 = Ctx(True)                                               # the caller is profiling: not switched, not switched off
+    c2 = mrc._StageClock(ctx2, True); c2.close()
+    assert ctx2.calls == [] and ctx2.prof_on
+    c3 = mrc._StageClock(Ctx(False), False)                        # no timing_data: nothing happens
+    assert c3.lap() == {} and c3.ctx.calls == []
