@@ -575,6 +575,179 @@ __global__ __launch_bounds__(64 * NW) void resize_mm_panel_kernel(const uint8_t 
     }
 }
 
+// Both passes in one workgroup: the horizontal pass of a run of lines stays in LDS (transposed, one
+// row per output byte, px - 128 like the panel) and the vertical pass reads its operands from there,
+// so the pass-to-pass image (a third of the page at scale 3, written and read back by the two-kernel
+// form) never goes to memory.  A workgroup = 8 horizontal tiles (128 output bytes) x NB blocks of RV
+// vertical tiles (16 RV output rows each).  It streams the lines those rows have taps on in groups of
+// 16 exactly as the panel kernel does; the transposed rows are a ring of 17 chunks of 16 lines (a
+// block spans at most 256 lines, ThumbPlan_build), so consecutive blocks share the lines of the
+// filter support instead of reading them again.  When the last line of a block is in, wave w takes
+// vertical tile w % RV and every (8 / RV)th horizontal tile: one vertical B operand per wave, used
+// 8 / RV times.  Chunks of a 64-line operand block that lie past the block's last line hold older
+// lines; their coefficients are zero.
+template <int KBH, int KBV, int RV>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void resize_mm_fused_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
+                                                               int line_bytes, uint8_t *dst, int dpitch, size_t dstride,
+                                                               int nout_h, int ntiles_h, const int32_t *kbase_h,
+                                                               const int32_t *bias_h, const v4i *bt_h, int nout_v,
+                                                               int ntiles_v, const int32_t *kbase_v, const int32_t *kend_v,
+                                                               const int32_t *bias_v, const v4i *bt_v, int gx, int gy, int gz,
+                                                               int panel_w, int pws, int nb) {
+    constexpr int NW = 8, TSTR = 272, RING = TSTR / 16;
+    const int total = gx * gy * gz, per = (total + 7) >> 3;            // XCD-contiguous work order (see resize_mm_kernel)
+    const int V = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (V >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int bx = V % gx, by = (V / gx) % gy, bz = V / (gx * gy);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *inP = smem;                                        // [2][16][pws]
+    unsigned char *T = smem + 2 * 16 * pws;                           // [128][TSTR]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nn = lane & 15, kq = lane >> 4;
+    src += (size_t)bz * sstride;
+    dst += (size_t)bz * dstride;
+    const int tile0 = bx * NW;
+    const int tvA = by * nb * RV, tvZ = min(tvA + nb * RV, ntiles_v);   // vertical tiles of this workgroup
+    const int Lb = kbase_v[tvA];                                      // multiple of 16
+    const int gtot = max((min(kend_v[tvZ - 1], nlines) - Lb + 15) >> 4, 1);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);               // wave-uniform copy (scalar register)
+    const int tile = tile0 + wvu;
+    const bool active = tile < ntiles_h;
+    v4i B[KBH][3];
+    auto load_bh = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < KBH; kb++)
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                B[kb][d] = bt_h[((size_t)(min(tile, ntiles_h - 1) * KBH + kb) * 3 + d) * 64 + lane];
+        // waited for here, once per block, not at its first use inside the line loop (where the wait would take the
+        // loads of the coming groups with it)
+#pragma unroll
+        for (int kb = 0; kb < KBH; kb++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) asm volatile("" : "+v"(B[kb][d]));
+    };
+    const int bs = active ? bias_h[tile * 16 + nn] : 0;
+    const int kbP = kbase_h[tile0];
+    const int koff = active ? kbase_h[tile] - kbP : 0;
+    // Every lane loads and stores in every group, with no branch around either: the compiler then counts the loads
+    // in flight (s_waitcnt vmcnt(1) for the group at hand while the next one is on its way) instead of waiting for
+    // all of them.  Lanes beyond the 16 x cpl chunks of a group repeat the first ones (same bytes to the same place);
+    // chunks that start past the end of a line hold no tap (zero coefficients) and take the line's last chunk instead,
+    // which keeps the reads inside the line (see resize_mm_panel_kernel).
+    const int cpl = panel_w >> 4;
+    const int lt = tid % (16 * cpl);
+    const int ld_line = lt / cpl, ld_chunk = lt - ld_line * cpl;
+    const unsigned colofs = kbP + min(ld_chunk, (line_bytes - 1 - kbP) >> 4) * 16;
+    const int pofs = ld_line * pws + ld_chunk * 16;
+    auto gload = [&](int g) -> v4i {                                  // 32-bit lane offset from the (scalar) page base
+        const int line = min(Lb + g * 16 + ld_line, nlines - 1);
+        return *reinterpret_cast<const v4i_u1 *>(src + ((unsigned)line * (unsigned)spitch + colofs));
+    };
+    v4i stage[2];
+    stage[0] = gload(0);
+    stage[1] = gload(min(1, gtot - 1));
+    load_bh();                                                        // (after the first lines are on their way)
+    unsigned char *trow = T + (wv * 16 + nn) * TSTR + kq * 4;
+
+    auto group = [&](int g, auto par) {
+        constexpr int P = decltype(par)::value;
+        unsigned char *ip = inP + P * 16 * pws;
+        *reinterpret_cast<v4i *>(ip + pofs) = stage[P] ^ (int)0x80808080;
+        stage[P] = gload(min(g + 2, gtot - 1));
+        lds_barrier();
+        if (active) {
+            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < KBH; kb++) {
+                const v4i x = *reinterpret_cast<const v4i *>(ip + nn * pws + koff + kb * 64 + kq * 16);
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][2], acc2, 0, 0, 0);
+            }
+            unsigned packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bs);
+                int qv = min(max(ss >> 22, 0), 255);                     // Resample.c clip8 (the 8-bit image between the passes)
+                asm volatile("" : "+v"(qv));                             // no v_ashr_pk_u8_i32 (see resize_mm_kernel)
+                packed |= (unsigned)qv << (8 * i);
+            }
+            // lines 16 g + 4 kq .. + 3 of output byte nn: row stride 68 dwords -> the 64 lanes hit 64 banks
+            *reinterpret_cast<unsigned *>(trow + (g % RING) * 16) = packed ^ 0x80808080u;
+        }
+    };
+    // vertical pass of the block of tiles tv0 .. tv0 + RV - 1 (all their lines are in the ring)
+    // vertical pass of the block of tiles tv0 .. tv0 + RV - 1 (all their lines are in the ring).  One base-256 digit of
+    // the coefficients at a time -- two operand registers quads instead of six -- so that the horizontal operand can
+    // stay in its registers (loading it again after every block cost a third more memory traffic: the tables of a
+    // 4000-pixel line are 1.5 MB and do not stay in L2 next to the page stream).
+    auto vblock = [&](int tv0) {
+        lds_barrier();
+        // lane indices behind an opaque copy: nothing of this block is computed ahead and kept in registers across the line loop
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int nv = lane_v & 15, kv = lane_v >> 4;
+        const int tv = tv0 + wvu % RV;
+        if (tv >= tvZ) return;
+        const unsigned bsv = (unsigned)bias_v[tv * 16 + nv];
+        const int c0 = ((kbase_v[tv] - Lb) >> 4) + kv;                // first chunk of this lane, before the ring wraps
+        int coff[KBV];
+#pragma unroll
+        for (int kb = 0; kb < KBV; kb++) coff[kb] = ((c0 + kb * 4) % RING) * 16;
+        const int row = tv * 16 + nv;
+        const v4i *bv = bt_v + (size_t)tv * KBV * 3 * 64 + lane_v;
+#pragma unroll 1
+        for (int ht = wvu / RV; ht < NW; ht += NW / RV) {
+            if (tile0 + ht >= ntiles_h) break;
+            const unsigned char *tp = T + (ht * 16 + nv) * TSTR;
+            unsigned ss[4] = {bsv, bsv, bsv, bsv};
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                v4i acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int kb = 0; kb < KBV; kb++)                  // (the line operand is read again for every digit: LDS is idle here)
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i *>(tp + coff[kb]), bv[(kb * 3 + d) * 64], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ss[i] += (unsigned)acc[i] << (8 * d);
+                __builtin_amdgcn_sched_barrier(0);                // one digit's operand registers at a time
+            }
+            unsigned packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int qv = min(max((int)ss[i] >> 22, 0), 255);
+                asm volatile("" : "+v"(qv));
+                packed |= (unsigned)qv << (8 * i);
+            }
+            // output row 16 tv + nn, bytes 16 (tile0 + ht) + 4 kq .. + 3 (the eight waves fill 128-byte runs of a row)
+            const int b0 = (tile0 + ht) * 16 + kv * 4;
+            if (row < nout_v && b0 < nout_h) {
+                uint8_t *o = dst + ((unsigned)row * (unsigned)dpitch + (unsigned)b0);
+                typedef unsigned u32_u1 __attribute__((aligned(1)));
+                if (b0 + 4 <= nout_h) *reinterpret_cast<u32_u1 *>(o) = packed;
+                else
+                    for (int i = 0; b0 + i < nout_h; i++) o[i] = (uint8_t)(packed >> (8 * i));
+            }
+        }
+    };
+    // the line stream may be one group past a block's last line when its vertical pass runs (groups go in
+    // pairs): the ring has room, a block spans at most 16 of its 17 chunks
+    int tvb = tvA;                                                     // next block to finish
+    auto gend = [&](int tv0) { return max((min(kend_v[min(tv0 + RV, tvZ) - 1], nlines) - Lb + 15) >> 4, 1); };
+    int ge = gend(tvb);
+    // (always whole pairs, so that the loads in flight are the same two at the top of every iteration: a last odd
+    // group is followed by a repeat of itself into the ring's spare chunk)
+    for (int g = 0; g < gtot; g += 2) {
+        group(g, std::integral_constant<int, 0>());
+        group(g + 1, std::integral_constant<int, 1>());
+        while (tvb < tvZ && g + 2 >= ge) {
+            vblock(tvb);
+            tvb += RV;
+            ge = tvb < tvZ ? gend(tvb) : INT_MAX;
+        }
+    }
+}
+
 // B operand, kbase and bias of one pass.  cs: byte stride between the taps of one output (the
 // channel count for the horizontal pass over interleaved pixels, 1 for the vertical pass).
 static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32_t> &kk, int ksize, int nout_px, int cs,
@@ -583,6 +756,7 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
     t.nout = nout_px * cs;
     t.ntiles = cdiv(t.nout, 16);
     t.kbase.assign(t.ntiles, 0);
+    t.kend.assign(t.ntiles, 0);
     t.bias.assign((size_t)t.ntiles * 16, 0);
     // first input byte of a tile, aligned down to 16 bytes when two 64-byte blocks still cover the tile
     // (aligned bases allow the workgroup-wide panel loads; a third MFMA block is not worth it), else as
@@ -601,6 +775,7 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
             if (hi < 0) { lo = 0; hi = 0; }
             lo &= ~(kalign - 1);
             t.kbase[T] = lo;
+            t.kend[T] = hi + 1;
             KB = std::max(KB, cdiv(hi - lo + 1, 64));
         }
         int KB1 = 1;                                            // blocks needed without any alignment
@@ -619,6 +794,7 @@ static bool build_mm(const std::vector<int32_t> &bounds, const std::vector<int32
     }
     if (KB > 2) return false;
     t.KB = KB;
+    for (int T = 1; T < t.ntiles; T++) t.kend[T] = std::max(t.kend[T], t.kend[T - 1]);
     // span of the 16 tiles of a workgroup (panel kernel)
     t.panel_w = 0;
     t.panel_w8 = 0;
@@ -712,6 +888,21 @@ int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h, int
             p.off_mm[i][0] = put(mm[i]->kbase.data(), mm[i]->kbase.size() * 4);
             p.off_mm[i][1] = put(mm[i]->bias.data(), mm[i]->bias.size() * 4);
             p.off_mm[i][2] = put(mm[i]->b.data(), mm[i]->b.size());
+            p.off_mmend[i] = put(mm[i]->kend.data(), mm[i]->kend.size() * 4);
+        }
+        // both passes in one kernel (resize_mm_fused_kernel): the horizontal panel must fit its 512 loader lanes
+        // and the vertical tile bases must be 16-byte aligned (they index LDS rows read as 16-byte operands);
+        // RV = vertical tiles per block, as many as keep the lines of a block within 16 of the 17 chunks of the LDS ring
+        p.fuse_rv = 0;
+        if (!getenv("MRCHIP_THUMB_NO_FUSE") && p.mmh.kalign == 16 && p.mmh.panel_w8 <= 512 && p.mmv.kalign == 16) {
+            for (int rv = 4; rv >= 1 && !p.fuse_rv; rv /= 2) {
+                int span = 0;
+                for (int t0 = 0; t0 < p.mmv.ntiles; t0 += rv) {
+                    const int t1 = std::min(t0 + rv, p.mmv.ntiles) - 1;
+                    span = std::max(span, round_up(p.mmv.kend[t1] - p.mmv.kbase[t0], 16));
+                }
+                if (span <= 256) p.fuse_rv = rv;
+            }
         }
     }
     p.blob_.resize(p.blob_.size() + 64);
@@ -768,6 +959,38 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
     auto tptr = [&](size_t off) { return reinterpret_cast<const int32_t *>(tb + off); };
     const int32_t *d_bh = tptr(p.off_bh), *d_kh = tptr(p.off_kh), *d_bv = tptr(p.off_bv), *d_kv = tptr(p.off_kv);
     const int32_t *d_khT = tptr(p.off_khT);
+    // (the fused kernel addresses a page with 32-bit lane offsets)
+    if (p.mm_ok && p.fuse_rv && (size_t)ch_ * cur.pitch < ((size_t)1 << 32) && (size_t)p.oh * dst.pitch < ((size_t)1 << 32)) {
+        const ThumbPlan::Mm &H = p.mmh, &Vt = p.mmv;
+        const int pw = H.panel_w8;
+        int pws = pw + 16;
+        if (((pws >> 4) & 1) == 0) pws += 16;
+        const int rv = p.fuse_rv;
+        const size_t lds = (size_t)2 * 16 * pws + (size_t)128 * 272;
+        const int gx = cdiv(H.ntiles, 8), nblk = cdiv(Vt.ntiles, rv);
+        // blocks per workgroup: as long a run of lines as still leaves some twenty rounds of workgroups (768 run at a time)
+        static const int nb_env = getenv("MRCHIP_FUSE_NB") ? atoi(getenv("MRCHIP_FUSE_NB")) : 0;
+        int nb = 1;
+        while (nb < nblk && (size_t)gx * cdiv(nblk, nb * 2) * npages >= 16384) nb *= 2;
+        if (nb_env > 0) nb = nb_env;
+        const int gy = cdiv(nblk, nb);
+        const dim3 grid(round_up(gx * gy * npages, 8));
+        const v4i *bth = reinterpret_cast<const v4i *>(tb + p.off_mm[0][2]), *btv = reinterpret_cast<const v4i *>(tb + p.off_mm[1][2]);
+#define MMF_LAUNCH(KH, KV, RVV)                                                                                              \
+    LAUNCH(ctx, s, "thumb_resize", red ? 0.0 : alg,                                                                          \
+           hipLaunchKernelGGL((resize_mm_fused_kernel<KH, KV, RVV>), grid, dim3(512), lds, s, cur.p, cur.pitch, cur.stride,  \
+                              ch_, cw * c, dst.p, dst.pitch, dst.stride, H.nout, H.ntiles, tptr(p.off_mm[0][0]),             \
+                              tptr(p.off_mm[0][1]), bth, Vt.nout, Vt.ntiles, tptr(p.off_mm[1][0]), tptr(p.off_mmend[1]),     \
+                              tptr(p.off_mm[1][1]), btv, gx, gy, npages, pw, pws, nb))
+#define MMF_RV(KH, KV) do { if (rv == 4) MMF_LAUNCH(KH, KV, 4); else if (rv == 2) MMF_LAUNCH(KH, KV, 2); else MMF_LAUNCH(KH, KV, 1); } while (0)
+        if (H.KB == 1 && Vt.KB == 1) MMF_RV(1, 1);
+        else if (H.KB == 1) MMF_RV(1, 2);
+        else if (Vt.KB == 1) MMF_RV(2, 1);
+        else MMF_RV(2, 2);
+#undef MMF_RV
+#undef MMF_LAUNCH
+        return 0;
+    }
     if (p.mm_ok) {
         // horizontal: lines = image rows -> scratch2 transposed [output byte][row]; vertical: lines = those -> dst
         static const int qpw_env = getenv("MRCHIP_MM_QPW") ? atoi(getenv("MRCHIP_MM_QPW")) : 0;      // tuning knob

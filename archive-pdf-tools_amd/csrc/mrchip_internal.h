@@ -285,13 +285,14 @@ struct ThumbPlan {
     // the 22-bit coefficients, already in lane order).
     struct Mm {
         int ntiles = 0, KB = 0, nout = 0, kalign = 1, panel_w = 0, panel_w8 = 0;   // panel_w / panel_w8: input bytes spanned by 16 / 8 consecutive tiles
-        std::vector<int32_t> kbase, bias; std::vector<unsigned char> b;
+        std::vector<int32_t> kbase, kend, bias; std::vector<unsigned char> b;     // kend: one past the last input byte a tile has a tap on (running maximum)
     };
     Mm mmh, mmv;
+    int fuse_rv = 0;          // > 0: both passes in one kernel, this many vertical tiles per workgroup
     int mm_ok = 0;            // both passes present and each 16-output tile spans <= 128 input bytes
     // every table in one blob (what the device copy holds), byte offsets of the parts
     std::vector<unsigned char> blob_;
-    size_t off_bh = 0, off_kh = 0, off_bv = 0, off_kv = 0, off_khT = 0, off_mm[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    size_t off_bh = 0, off_kh = 0, off_bv = 0, off_kv = 0, off_khT = 0, off_mm[2][3] = {{0, 0, 0}, {0, 0, 0}}, off_mmend[2] = {0, 0};
 };
 int ThumbPlan_build(ThumbPlan &p, int w, int h, int c, int req_w, int req_h, int filter = 0 /* MRCHIP_FILTER_BICUBIC */,
                     double reducing_gap = 2.0);

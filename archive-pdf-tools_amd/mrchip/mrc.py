@@ -740,7 +740,7 @@ _STAGE_KERNELS = {
     'threshold': ('sauvola',),
     'fast_denoise': ('denoise_pack', 'denoise_solve', 'denoise_reconcile', 'denoise_unpack', 'denoise_jacobi', 'mask_pack_bits'),
     'partial_blur': ('optimise_rgb', 'optimise_gray'),
-    'downsample': ('thumb_reduce', 'thumb_resize_h', 'thumb_resize_v', 'thumb_resize_mm'),
+    'downsample': ('thumb_reduce', 'thumb_resize', 'thumb_resize_h', 'thumb_resize_v', 'thumb_resize_mm'),
 }
 
 

@@ -190,6 +190,21 @@ def test_thumbnail_golden_and_random():
         assert got.shape == exp.shape and np.array_equal(got, exp), (h, w, f, c)
 
 
+@pytest.mark.parametrize('env', [{'MRCHIP_THUMB_NO_FUSE': '1'}, {'MRCHIP_FUSE_NB': '2'}, {'MRCHIP_FUSE_NB': '3'},
+                                 {'MRCHIP_FUSE_NB': '16'}])
+def test_thumbnail_other_schedules(env):
+    """The same vectors through the two-kernel form (pass-to-pass image in memory) and through the one-kernel form with
+    2, 3 and 16 blocks of output rows per workgroup (the LDS ring of lines wraps; small inputs take 1 by default).
+    The switches are read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-k',
+                        'test_thumbnail_golden_and_random', '-p', 'no:cacheprovider'],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 # ---- hOCR box mask ------------------------------------------------------------------------
 def test_hocr_mask_vs_oracle():
     for seed, ns, dpi in [(0, 6.0, None), (1, 2.0, 150), (2, 12.0, None), (3, 0.0, 300)]:
