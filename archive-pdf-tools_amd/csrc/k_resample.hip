@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mm_panel_kernel(const uint8_t 
 // 8 / RV times.  Chunks of a 64-line operand block that lie past the block's last line hold older
 // lines; their coefficients are zero.
 template <int KBH, int KBV, int RV>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void resize_mm_fused_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
+__global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src, int spitch, size_t sstride, int nlines,
                                                                int line_bytes, uint8_t *dst, int dpitch, size_t dstride,
                                                                int nout_h, int ntiles_h, const int32_t *kbase_h,
                                                                const int32_t *bias_h, const v4i *bt_h, int nout_v,
@@ -613,6 +613,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int wvu = __builtin_amdgcn_readfirstlane(wv);               // wave-uniform copy (scalar register)
     const int tile = tile0 + wvu;
     const bool active = tile < ntiles_h;
+    // the horizontal B operand is loaded again after every vertical block: its registers carry the vertical operand
+    // meanwhile, which keeps the kernel at six waves per SIMD (three workgroups per CU)
     v4i B[KBH][3];
     auto load_bh = [&]() {
 #pragma unroll
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
             for (int d = 0; d < 3; d++) asm volatile("" : "+v"(B[kb][d]));
     };
+    load_bh();
     const int bs = active ? bias_h[tile * 16 + nn] : 0;
     const int kbP = kbase_h[tile0];
     const int koff = active ? kbase_h[tile] - kbP : 0;
@@ -647,7 +650,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     v4i stage[2];
     stage[0] = gload(0);
     stage[1] = gload(min(1, gtot - 1));
-    load_bh();                                                        // (after the first lines are on their way)
     unsigned char *trow = T + (wv * 16 + nn) * TSTR + kq * 4;
 
     auto group = [&](int g, auto par) {
@@ -678,10 +680,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
     };
     // vertical pass of the block of tiles tv0 .. tv0 + RV - 1 (all their lines are in the ring)
-    // vertical pass of the block of tiles tv0 .. tv0 + RV - 1 (all their lines are in the ring).  One base-256 digit of
-    // the coefficients at a time -- two operand registers quads instead of six -- so that the horizontal operand can
-    // stay in its registers (loading it again after every block cost a third more memory traffic: the tables of a
-    // 4000-pixel line are 1.5 MB and do not stay in L2 next to the page stream).
+    // vertical pass of the block of tiles tv0 .. tv0 + RV - 1 (all their lines are in the ring)
     auto vblock = [&](int tv0) {
         lds_barrier();
         // lane indices behind an opaque copy: nothing of this block is computed ahead and kept in registers across the line loop
@@ -690,32 +689,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int nv = lane_v & 15, kv = lane_v >> 4;
         const int tv = tv0 + wvu % RV;
         if (tv >= tvZ) return;
-        const unsigned bsv = (unsigned)bias_v[tv * 16 + nv];
+        v4i Bv[KBV][3];
+#pragma unroll
+        for (int kb = 0; kb < KBV; kb++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) Bv[kb][d] = bt_v[((size_t)(tv * KBV + kb) * 3 + d) * 64 + lane_v];
+        const int bsv = bias_v[tv * 16 + nv];
         const int c0 = ((kbase_v[tv] - Lb) >> 4) + kv;                // first chunk of this lane, before the ring wraps
         int coff[KBV];
 #pragma unroll
         for (int kb = 0; kb < KBV; kb++) coff[kb] = ((c0 + kb * 4) % RING) * 16;
         const int row = tv * 16 + nv;
-        const v4i *bv = bt_v + (size_t)tv * KBV * 3 * 64 + lane_v;
 #pragma unroll 1
         for (int ht = wvu / RV; ht < NW; ht += NW / RV) {
             if (tile0 + ht >= ntiles_h) break;
-            const unsigned char *tp = T + (ht * 16 + nv) * TSTR;
-            unsigned ss[4] = {bsv, bsv, bsv, bsv};
+            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                v4i acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int kb = 0; kb < KBV; kb++)                  // (the line operand is read again for every digit: LDS is idle here)
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const v4i *>(tp + coff[kb]), bv[(kb * 3 + d) * 64], acc, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) ss[i] += (unsigned)acc[i] << (8 * d);
-                __builtin_amdgcn_sched_barrier(0);                // one digit's operand registers at a time
+            for (int kb = 0; kb < KBV; kb++) {
+                const v4i x = *reinterpret_cast<const v4i *>(T + (ht * 16 + nv) * TSTR + coff[kb]);
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, Bv[kb][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, Bv[kb][1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, Bv[kb][2], acc2, 0, 0, 0);
             }
             unsigned packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                int qv = min(max((int)ss[i] >> 22, 0), 255);
+                const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bsv);
+                int qv = min(max(ss >> 22, 0), 255);
                 asm volatile("" : "+v"(qv));
                 packed |= (unsigned)qv << (8 * i);
             }
@@ -744,6 +744,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             vblock(tvb);
             tvb += RV;
             ge = tvb < tvZ ? gend(tvb) : INT_MAX;
+            load_bh();
         }
     }
 }
