@@ -86,6 +86,12 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         if self.saved is not None:
+            # what the native code printf'ed sits in C stdio's buffer when stdout is a pipe or a file: push it out
+            # while fd 1 still points at stderr, or it lands on the real stdout at exit (after bench.py's JSON line)
+            try:
+                C.CDLL(None).fflush(None)
+            except OSError:
+                pass
             os.dup2(self.saved, 1)
             os.close(self.saved)
             self.saved = None

@@ -185,3 +185,24 @@ def test_make_comm_require_rccl_raises_on_every_rank(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 3, (so, se[-1000:])
         assert 'MRCHIP_REQUIRE_RCCL' in so
+
+
+def test_native_stdout_banner_goes_to_stderr_even_when_buffered():
+    """What native code printf's inside the redirection (RCCL's version banner) must not reach the real stdout later:
+    with stdout a pipe C stdio holds it in its buffer until exit, i.e. until after bench.py's JSON line, unless the
+    redirection flushes it while fd 1 still points at stderr."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes\n"
+        "sys.path.insert(0, %r)\n"
+        "from mrchip import dist\n"
+        "libc = ctypes.CDLL(None)\n"
+        "with dist._stdout_to_stderr(True):\n"
+        "    libc.printf(b'BANNER from native code\\n')\n"
+        "print('{\"the\": \"line\"}')\n"
+    ) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'archive-pdf-tools_amd')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip() == '{"the": "line"}', r.stdout
+    assert 'BANNER from native code' in r.stderr
