@@ -575,6 +575,17 @@ __global__ __launch_bounds__(64 * NW) void resize_mm_panel_kernel(const uint8_t 
     }
 }
 
+// Four results of a pass -> four bytes: clip8(s >> 22) of each, packed.  v_ashr_pk_u8_i32 does a pair per instruction
+// ({sat_u8(S0 >> n), sat_u8(S1 >> n)} into one half of the destination, the other half keeps its bits -- which is why
+// the compiler must not form it on its own, see resize_mm_kernel: hipcc 7.2 takes the other half for zero); op_sel[3]
+// picks the upper half.  Measured on the part (byte order, saturation at both ends, the preserved half).
+__device__ __forceinline__ unsigned clip8x4_shr22(const int (&s)[4]) {
+    unsigned d = 0;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "+v"(d) : "v"(s[0]), "v"(s[1]));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 22 op_sel:[0,0,0,1]" : "+v"(d) : "v"(s[2]), "v"(s[3]));
+    return d;
+}
+
 // Both passes in one workgroup: the horizontal pass of a run of lines stays in LDS (transposed, one
 // row per output byte, px - 128 like the panel) and the vertical pass reads its operands from there,
 // so the pass-to-pass image (a third of the page at scale 3, written and read back by the two-kernel
@@ -667,14 +678,11 @@ __global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src
                 acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][1], acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, B[kb][2], acc2, 0, 0, 0);
             }
-            unsigned packed = 0;
+            int ss[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bs);
-                int qv = min(max(ss >> 22, 0), 255);                     // Resample.c clip8 (the 8-bit image between the passes)
-                asm volatile("" : "+v"(qv));                             // no v_ashr_pk_u8_i32 (see resize_mm_kernel)
-                packed |= (unsigned)qv << (8 * i);
-            }
+            for (int i = 0; i < 4; i++)
+                ss[i] = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bs);
+            const unsigned packed = clip8x4_shr22(ss);                   // Resample.c clip8 (the 8-bit image between the passes)
             // lines 16 g + 4 kq .. + 3 of output byte nn: row stride 68 dwords -> the 64 lanes hit 64 banks
             *reinterpret_cast<unsigned *>(trow + (g % RING) * 16) = packed ^ 0x80808080u;
         }
@@ -711,14 +719,11 @@ __global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src
                 acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, Bv[kb][1], acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, Bv[kb][2], acc2, 0, 0, 0);
             }
-            unsigned packed = 0;
+            int ss[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int ss = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bsv);
-                int qv = min(max(ss >> 22, 0), 255);
-                asm volatile("" : "+v"(qv));
-                packed |= (unsigned)qv << (8 * i);
-            }
+            for (int i = 0; i < 4; i++)
+                ss[i] = (int)((unsigned)acc0[i] + ((unsigned)acc1[i] << 8) + ((unsigned)acc2[i] << 16) + (unsigned)bsv);
+            const unsigned packed = clip8x4_shr22(ss);
             // output row 16 tv + nn, bytes 16 (tile0 + ht) + 4 kq .. + 3 (the eight waves fill 128-byte runs of a row)
             const int b0 = (tile0 + ht) * 16 + kv * 4;
             if (row < nout_v && b0 < nout_h) {
