@@ -28,6 +28,23 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *
     return 0;
 }
 
+MRCHIP_EXPORT int mrchip_selftest_sauvola_table(mrchip_ctx *ctx, double k, double R, long long *mismatches, long long *tested,
+                                                int *table_bytes) {
+    CHECK_CTX(ctx);
+    if (!mismatches || !tested) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    DevBuf bad;
+    TRY(bad.alloc(ctx, 256));
+    TRY(sauvola_table_selftest(ctx, s, k, R, bad.as<unsigned long long>(), table_bytes));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, bad.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *mismatches = (long long)h[0];
+    *tested = (long long)h[1];
+    return 0;
+}
+
 MRCHIP_EXPORT int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches) {
     CHECK_CTX(ctx);
     if (!mismatches) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }

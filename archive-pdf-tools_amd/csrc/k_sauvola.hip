@@ -29,14 +29,14 @@
 
 namespace mrchip {
 
-// Per window-row-count constants of the table-driven decision (one record per nrows = 1..wh, count = ww * nrows):
-// exact truncating divisions by `count` as one 32x32->hi multiply + shift each (host-checked magic numbers).
+// Per window-row-count constants (one record per nrows = 1..wh, count = ww * nrows): the exact truncating mean
+// floor(S / count) as one 32x32->hi multiply + shift (host-checked magic number).
 struct SauvolaRow {
-    unsigned ms, mq;          // floor(S / count) = mulhi(S, ms) >> ss  for 0 <= S <= 255 count;  likewise Q <= 65025 count
-    int ss, sq;
+    unsigned ms;              // floor(S / count) = mulhi(S, ms) >> ss  for 0 <= S <= 255 count
+    int ss;
     unsigned c255, c65025;    // 255 * count, 65025 * count: window sums of the inverted image (255 - p)
-    int ok;                   // magic numbers exist for this count
-    int pad_;
+    int ok;                   // a magic number exists for this count and 65026 * count < 2^32
+    int pad_[3];
 };
 
 struct SauvolaParams {
@@ -46,11 +46,15 @@ struct SauvolaParams {
     int flags;
     int two;          // output columns per tile
     int th;           // output rows per tile
-    // table-driven decision (see sauvola_kernel): per-row magic numbers; fast == 0: quotients in fp64 for every pixel
-    int fast;
+    int strips, ytiles;       // tiles of the largest job (table kernel: a workgroup's waves take consecutive tiles)
     const SauvolaRow *rows;   // [wh + 1], indexed by nrows
+    // ---- table-driven decision (sauvola_tab_kernel) ----
+    const unsigned short *tab;   // [256][tabW]: T2[mean][clamp(px - mean, dlo1, dhi1) - dlo1]
+    int tab_bytes;               // multiple of 16
+    int tabW, dlo1, dhi1;
+    const uint4 *colrec;         // [ww + 1] {ms, ss, count, ok} for count = ncols * wh: strips at the left / right border
+    int colrec_n, colrec_ok;
 };
-
 
 // inclusive wave scan (64 lanes) with DPP row shifts + row broadcasts (GFX9)
 __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
@@ -150,53 +154,89 @@ __device__ __forceinline__ unsigned slot_dword(const typename Slot<KD>::T &r, in
     if constexpr (KD == 1) return r; else return r[q];
 }
 
-// Per wave: a strip of CW = 64*K input columns by `rows` output rows (tall tiles amortise the
+// ---- the table-driven decision (k >= 0) ------------------------------------------------------------------------
+// For an integer mean m = S / count (truncating, pyx:144) and a pixel px the reference's decision (pyx:143-151)
+//     tmp = px + m (k - 1);  form = tmp <= 0  or  tmp tmp <= ((m m) k2) var,      var = Q / count - m m
+// depends on the window only through the INTEGER var in 0 .. 65025, and fl(A var) is monotone in var for A >= 0:
+// there is a smallest Vmin(m, px) with form <=> var >= Vmin (0 where tmp <= 0, "never" where no var <= vmax(m)
+// satisfies it).  With T2 = Vmin + m m:   form  <=>  floor(Q / count) >= T2  <=>  Q >= count T2   -- no division
+// of Q, no conversion, no fp64 operation.  The table is built on the device with the very predicate of the general path
+// (sauvola_form_dd) by bisection over var, per (k, R), and checked exhaustively against it (every (m, px, var):
+// mrchip_selftest_sauvola_table).  "always" is stored as 0, "never" as 65026 (count 65026 < 2^32 > any Q).
+// Reachable variances: every pixel is <= 255, so Q <= 255 S, floor(Q / count) <= min(65025, 255 m + 254) and var <=
+// vmax(m) = min(65025, 255 m + 254) - m m; entries whose Vmin lies above that are "never" (so T2 <= 65025 otherwise).  That bounds the band of (m, px) whose entry is
+// neither constant to d = px - m in [dlo, dhi] (k = 0.34, R = 128: -86 .. 0), and the LDS copy is
+//     tab[m][clamp(px - m, dlo - 1, dhi + 1) - (dlo - 1)]    (16 bits each; 45 KB for k = 0.34, 14 KB for k = 0.1)
+// whose first / last column are the constants.  Per pixel: mul_hi + bfe (mean), sub, med3, mad + lshl_add (address),
+// ds_read_u16, mul_u24, compare, addc.
+__device__ __forceinline__ bool sauvola_pred(double mean, double px, double var, double km1, double k2) {
+    // the general path's function on count = 1: S = mean, Q = var + mean^2 (exact), 1 / count = 1
+    return sauvola_form_dd(mean, __dadd_rn(var, __dmul_rn(mean, mean)), px, 1.0, 0.5, true, km1, k2);
+}
+__device__ __forceinline__ int sauvola_vmax(int m) { return min(65025, 255 * m + 254) - m * m; }
+
+// full[m][px] = T2 (0 always, 65026 never)
+__global__ __launch_bounds__(256) void sauvola_t2_build_kernel(unsigned short *full, double km1, double k2) {
+    const int m = blockIdx.x, px = threadIdx.x;
+    const int vmax = sauvola_vmax(m);
+    int lo = 0, hi = vmax + 1;                 // smallest var in [0, vmax] with pred, vmax + 1 if none
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sauvola_pred((double)m, (double)px, (double)mid, km1, k2)) hi = mid; else lo = mid + 1;
+    }
+    full[m * 256 + px] = (unsigned short)(lo == 0 ? 0 : (lo > vmax ? 65026 : lo + m * m));
+}
+
+// every (m, px, var <= vmax(m)): the compact table (read with the kernel's own index arithmetic) against the predicate
+__global__ __launch_bounds__(256) void sauvola_t2_selftest_kernel(const unsigned short *tab, int W, int dlo1, int dhi1,
+                                                                  double km1, double k2, unsigned long long *bad,
+                                                                  unsigned long long *tested) {
+    const int m = blockIdx.x, px = threadIdx.x;
+    const int d = px - m;
+    const int j = min(max(d, dlo1), dhi1) - dlo1;
+    const unsigned T2 = tab[m * W + j];
+    const int vmax = sauvola_vmax(m);
+    unsigned long long nbad = 0;
+    for (int var = 0; var <= vmax; var++) {
+        const bool want = sauvola_pred((double)m, (double)px, (double)var, km1, k2);
+        const bool got = (unsigned)(var + m * m) >= T2;
+        nbad += want != got;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+    atomicAdd(tested, (unsigned long long)(vmax + 1));
+}
+
+// One tile: a strip of CW = 64*K input columns by `rows` output rows on one wave (tall tiles amortise the
 // (wh-1)-row warm-up).  (An LDS ring of the last wh rows was tried: it removes the re-reads but
 // caps the CU at ~10 waves and ran 2x slower -- occupancy is what hides this kernel's per-row chain.)
 // BOTH: every job also thresholds the image 255 - p (the hOCR-box launch; a page launch has BOTH = false and does
 // not carry the second polarity's registers).
-template <int K, bool MULTI, bool FAST, bool BOTH, int PL = 32>
-__global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
-                                                     SauvolaParams P) {
+// TAB: rows whose count has a magic number take the table-driven decision above -- with scalar operands where the
+// whole strip sees the full window width, with per-column records from LDS on strips at the left / right border
+// while the window has its full height; every other row (and the whole of a TAB = false launch: k < 0, a table
+// too large for LDS, MRCHIP_SAUVOLA_FAST=0) takes the reference's fp64 sequence.
+// ebase: LDS byte offset of this wave's prefix rows; tab_lds / rec_lds: of the workgroup's tables.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x2 __attribute__((address_space(3))) *lds_u2p;
+typedef u32x4 __attribute__((address_space(3))) *lds_u4p;
+typedef unsigned short __attribute__((address_space(3))) *lds_u16p;
+
+template <int K, bool TAB, bool BOTH, int PL>
+__device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const SauvolaParams &P, const unsigned ebase,
+                                             const unsigned tab_lds, const unsigned rec_lds, const int X0, const int Y0,
+                                             const int lane) {
     constexpr int KD = K / 4;
-#ifndef SAUVOLA_PF8
-#define SAUVOLA_PF8 2
-#endif
-    constexpr int PF = (K == 8) ? SAUVOLA_PF8 : 2;     // rows in flight = unroll factor of the row loop
+    constexpr int PF = 2;                              // rows in flight = unroll factor of the row loop
     // Prefix rows in LDS, transposed: strip column ci = K*t + i lives at [i][t + PL].  A wave's
-    // accesses for one pixel index i are then consecutive dwords (conflict-free); the natural
+    // accesses for one pixel index i are then consecutive 8-byte units (conflict-free); the natural
     // [ci] order would put lanes 16 B apart = a 4-way bank conflict on every read.  PL lanes of
     // slack on both sides: halo lanes evaluate the formula on out-of-strip indices instead of
     // branching around it (their results are never stored).  K * PL columns of slack must cover half a window:
-    // PL = 8 for the windows the pipeline uses (LDS per wave 5 KiB of prefix rows + 4 KiB of tables: 16 waves per CU
-    // fit), 32 for the widest ones.
-    constexpr int LS = 64 + 2 * PL;
+    // PL = 8 for the windows the pipeline uses, 32 for the widest ones.
     // (prefix of sums, prefix of sums of squares) side by side: one 8-byte LDS access per column end instead of two
-    __shared__ uint2 EBuf[K * LS];
-    auto pidx = [&](int ci) { const int c2 = ci + K * PL; return (c2 % K) * LS + c2 / K; };
-    // FAST: the two products of the reference's decision that depend on the (integer) mean only, for every mean
-    // 0..255, rounded exactly as the reference rounds them (pyx:147-150): mean * (k - 1) and (mean * mean) * k2.
-    // The decision then is: integer mean (index) -> two LDS reads -> add, two multiplies, two compares.
-    // (Measured: the tables save 3 VALU instructions per pixel but their per-lane LDS reads conflict on noisy images --
-    // 20 % of the LDS cycles -- and the kernel comes out 3 % slower on the c3gray batch, 7 % faster on blurred pages;
-    // computing the two products from the integer mean is the robust choice.  TABLES keeps the variant buildable.)
-    constexpr bool TABLES = false;
-    __shared__ double Tkm1[(FAST && TABLES) ? 256 : 1], Tk2[(FAST && TABLES) ? 256 : 1];
-    if constexpr (FAST && TABLES) {
-        for (int m = threadIdx.x; m < 256; m += 64) {
-            const double md = (double)m;
-            Tkm1[m] = __dmul_rn(md, P.km1);
-            Tk2[m] = __dmul_rn(__dmul_rn(md, md), P.k2);
-        }
-        lds_wave_sync();
-    }
-
-    SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
+    constexpr int LS = 64 + 2 * PL;
     const int w = job.w, h = job.h;
-    const int X0 = blockIdx.x * P.two;
-    const int Y0 = blockIdx.y * P.th;
-    if (X0 >= w || Y0 >= h) return;
-    const int lane = threadIdx.x;
     const int nout = min(P.two, w - X0);
     const int rows = min(P.th, h - Y0);
     const int l = P.l, r = P.r, o = P.o, u = P.u;
@@ -223,25 +263,21 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
     // all outputs of this strip see the full window width -> count is wave-uniform per row
     const bool full_cols = (X0 - l + 1 >= 0) && (X0 + nout - 1 + r <= w - 1);
 
+    // LDS addresses: this lane's slot of prefix row i is wbase + i * LS * 8; the two window ends of pixel i are
+    // strip columns ci + r + 1 and ci - l + 1 = (row (i + a) % K, slot lane + PL + a / K): lane part + a uniform part
+    const unsigned wbase = ebase + (unsigned)(lane + PL) * 8u;
+    auto uoff = [&](int i, int a) {                    // uniform: byte offset of strip column K*lane + i + a relative to wbase
+        const int c2 = i + a + K * PL;                 // >= 0: K * PL covers half a window
+        return (unsigned)(((c2 % K) * LS + c2 / K - PL) * 8);
+    };
+
+    // window column sums while the tile warms up, then (in place) the exclusive prefix over the strip's columns
     unsigned cs[K], cq[K];
 #pragma unroll
     for (int i = 0; i < K; i++) { cs[i] = 0; cq[i] = 0; }
 
-    auto acc_row = [&](const unsigned (&wv)[KD], bool plus) {
-#pragma unroll
-        for (int q = 0; q < KD; q++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                unsigned p = (wv[q] >> (8 * b)) & 0xffu;
-                if (plus) { cs[4 * q + b] += p; cq[4 * q + b] += p * p; }
-                else      { cs[4 * q + b] -= p; cq[4 * q + b] -= p * p; }
-            }
-        }
-    };
     // raw row from global memory (global, not flat, address space): the row index is clamped into
-    // the image and nothing touches the loaded registers here, so the load stays in flight until the
-    // row is USED several iterations later (masking at load time would put an s_waitcnt right here).
-    // Rows outside the image are skipped where they are used (wave-uniform tests).
+    // the image; rows outside the image are skipped where they are used (wave-uniform tests).
     typedef const unsigned __attribute__((address_space(1))) *gc_u32p;
     // wave-uniform row base (scalar registers) + the lane's 32-bit byte offset: the load takes the
     // SGPR-base addressing mode and costs no 64-bit vector address arithmetic
@@ -254,11 +290,16 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
 #pragma unroll
         for (int q = 0; q < KD; q++) wv[q] = p[q];
     };
-    auto acc_row_m = [&](const unsigned (&wv)[KD], bool plus) {
-        unsigned m[KD];
+    auto acc_row_m = [&](const unsigned (&wv)[KD]) {
 #pragma unroll
-        for (int q = 0; q < KD; q++) m[q] = wv[q] & vmask[q];
-        acc_row(m, plus);
+        for (int q = 0; q < KD; q++) {
+            const unsigned m = wv[q] & vmask[q];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned p = (m >> (8 * b)) & 0xffu;
+                cs[4 * q + b] += p; cq[4 * q + b] += p * p;
+            }
+        }
     };
     // warm-up: rows [Y0-o, Y0+u-1] (clipped) enter the sums, four loads in flight at a time
     {
@@ -269,13 +310,27 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
 #pragma unroll
             for (int t = 0; t < 4; t++) gload(yy + t, wv[t]);
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc_row_m(wv[t], true);
+            for (int t = 0; t < 4; t++) acc_row_m(wv[t]);
         }
         for (; yy < ye; yy++) {
             unsigned wv[KD];
             gload(yy, wv);
-            acc_row_m(wv, true);
+            acc_row_m(wv);
         }
+    }
+    // column sums -> exclusive prefix over the strip (lane-local prefix + wave scan of the lane totals).  From here on
+    // the registers hold the PREFIX: a row adds the prefix of its column deltas (one three-operand add per value)
+    // instead of updating K sums and prefixing them again.
+    {
+        unsigned ts = 0, tq = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const unsigned a = cs[i], b = cq[i];
+            cs[i] = ts; cq[i] = tq; ts += a; tq += b;
+        }
+        const unsigned bs = wave_scan_incl(ts) - ts, bq = wave_scan_incl(tq) - tq;
+#pragma unroll
+        for (int i = 0; i < K; i++) { cs[i] += bs; cq[i] += bq; }
     }
     // three register queues, PF slots each: entering rows y+u, leaving rows y-o, centre rows y.
     // Every address is known in advance, so the loads run PF rows ahead of their use and the
@@ -283,9 +338,9 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
     typedef typename Slot<KD>::T slot_t;
     slot_t qe[PF], ql[PF], qc[PF];
     const bool invert = (P.flags & SAUVOLA_INVERT) != 0;
-    auto aload = [&](int yy, slot_t &r) {
+    auto aload = [&](int yy, slot_t &rr) {
         const int yc = min(max(yy, 0), h - 1);
-        row_load_async<KD>(r, loff, srcA + (size_t)yc * job.src_pitch);     // uniform row base + lane offset
+        row_load_async<KD>(rr, loff, srcA + (size_t)yc * job.src_pitch);     // uniform row base + lane offset
     };
     // every load of the loop is issued in this order: e, l (after the column update), c (after the decision)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the warm-up's loads are the compiler's: start from zero
@@ -301,6 +356,22 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
     unsigned ones_a = 0, ones_b = 0;
     const bool kpos = P.k >= 0;
 
+    // table path: clamp bounds and the address constant in registers (a VALU instruction reads one scalar operand)
+    int dlo1v = P.dlo1, dhi1v = P.dhi1;
+    unsigned tabC = tab_lds - 2u * (unsigned)P.dlo1;
+    const unsigned tabW2 = 2u * (unsigned)P.tabW;
+    if constexpr (TAB) asm volatile("" : "+v"(dlo1v), "+v"(dhi1v), "+v"(tabC));
+    // strips at the left / right border: LDS address of the record of each of the lane's columns (count = ncols * wh)
+    unsigned recaddr[K];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const int c = c0 + i;
+            const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
+            recaddr[i] = rec_lds + 16u * (unsigned)min(max(ncols, 1), P.ww);
+        }
+    }
+
     // The row loop is unrolled PF times so that each slot of the three queues is a fixed set of registers: row y
     // reads slot y mod PF and, once it is done with it, loads row y + PF into the same registers.  No register
     // moves, and a load has PF - 1 whole rows to land (a shifting queue makes every row wait for the load issued
@@ -312,9 +383,11 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
         unsigned ev[KD], lv[KD], cv[KD];
 #pragma unroll
         for (int q = 0; q < KD; q++) { ev[q] = slot_dword<KD>(qev, q); lv[q] = slot_dword<KD>(qlv, q); }
-        // entering row y+u and leaving row y-o together: with d = pe - pl and t = pe + pl per column,
-        // S += d and Q += pe^2 - pl^2 = d * t (one signed 24-bit multiply-add); a row outside the image
-        // contributes zeros (wave-uniform selects)
+        // entering row y+u and leaving row y-o together: with d = pe - pl and t = pe + pl per column the column's
+        // S changes by d and its Q by pe^2 - pl^2 = d * t (one signed 24-bit multiply-add); es / eq = exclusive prefix
+        // of those deltas over the lane's columns, rs / rq their totals.  A row outside the image contributes zeros
+        // (wave-uniform selects)
+        unsigned es[K], eq[K], rs = 0, rq = 0;
         {
             const bool has_e = y + u < h, has_l = y - o >= 0;
 #pragma unroll
@@ -324,8 +397,9 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
                 for (int b = 0; b < 4; b++) {
                     const int pe = (int)((em >> (8 * b)) & 0xffu), pl = (int)((lm >> (8 * b)) & 0xffu);
                     const int d = pe - pl, t = pe + pl;
-                    cs[4 * q + b] += (unsigned)d;
-                    cq[4 * q + b] += (unsigned)__mul24(d, t);
+                    es[4 * q + b] = rs; eq[4 * q + b] = rq;
+                    rs += (unsigned)d;
+                    rq += (unsigned)__mul24(d, t);
                 }
             }
         }
@@ -333,7 +407,7 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
         // row's data: vmcnt counts in order, so a load issued before that wait is waited for as well (a full memory
         // latency in every row).  The barrier takes a result of the column update as an operand -- a bare "memory"
         // clobber orders memory operations only and lets the scheduler sink the (register-only) update below it.
-        asm volatile("" : "+v"(cs[K - 1]), "+v"(cq[0]) : : "memory");
+        asm volatile("" : "+v"(rs), "+v"(rq) : : "memory");
         aload(y + u + PF, qev);
         aload(y - o + PF, qlv);
         const int nrows = __builtin_amdgcn_readfirstlane(min(y + u, h - 1) - max(y - o, -1));
@@ -342,26 +416,23 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
             // vector load behind the kernel's own stores and put a full-latency vmcnt(0) into the row)
             typedef const SauvolaRow __attribute__((address_space(4))) *crow_p;
             const crow_p rp = (crow_p)(uintptr_t)P.rows + nrows;
-            RW.ms = rp->ms; RW.mq = rp->mq; RW.ss = rp->ss; RW.sq = rp->sq;
-            RW.c255 = rp->c255; RW.c65025 = rp->c65025; RW.ok = rp->ok;
+            RW.ms = rp->ms; RW.ss = rp->ss; RW.c255 = rp->c255; RW.c65025 = rp->c65025; RW.ok = rp->ok;
             cur_nrows = nrows;
         }
 
-        // exclusive prefix over the strip's columns
-        unsigned ps[K], pqx[K];
-        unsigned ts = 0, tq = 0;
-#pragma unroll
-        for (int i = 0; i < K; i++) { ps[i] = ts; pqx[i] = tq; ts += cs[i]; tq += cq[i]; }
-        unsigned bs = wave_scan_incl(ts) - ts;
-        unsigned bq = wave_scan_incl(tq) - tq;
+        // the row's prefix = previous prefix + prefix of the deltas (lane-local part + wave scan of the lane totals)
+        const unsigned dbs = wave_scan_incl(rs) - rs;
+        const unsigned dbq = wave_scan_incl(rq) - rq;
         lds_wave_sync();                   // previous row's LDS reads are done
 #pragma unroll
         for (int i = 0; i < K; i++) {
-            EBuf[i * LS + lane + PL] = make_uint2(bs + ps[i], bq + pqx[i]);
+            cs[i] = cs[i] + es[i] + dbs;
+            cq[i] = cq[i] + eq[i] + dbq;
+            *(lds_u2p)(uintptr_t)(wbase + (unsigned)(i * LS * 8)) = u32x2{cs[i], cq[i]};
         }
         lds_wave_sync();
 
-        // wave-uniform count / reciprocal when every output of the strip has the full window width
+        // wave-uniform count when every output of the strip has the full window width
         const unsigned ucount = (unsigned)(P.ww * nrows);
         rows_wait<WAIT_C>(qcv);            // the centre row, loaded PF rows ago
 #pragma unroll
@@ -371,17 +442,10 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
 #pragma unroll
         for (int q = 0; q < KD; q++) { outa[q] = 0; outb[q] = 0; }
 
-        // window sums and count of column i of this lane (S, Q exact integers mod 2^32)
-        auto window = [&](int i, unsigned &S, unsigned &Q, unsigned &count) {
-            const int c = c0 + i;
-            const int ci = K * lane + i;
-            const uint2 ea = EBuf[pidx(ci + r + 1)], eb = EBuf[pidx(ci - l + 1)];
+        // window sums of column i of this lane (S, Q exact integers mod 2^32)
+        auto window = [&](int i, unsigned &S, unsigned &Q) {
+            const u32x2 ea = *(lds_u2p)(uintptr_t)(wbase + uoff(i, r + 1)), eb = *(lds_u2p)(uintptr_t)(wbase + uoff(i, 1 - l));
             S = ea.x - eb.x; Q = ea.y - eb.y;
-            count = ucount;
-            if (!full_cols) {
-                const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
-                count = (unsigned)max(ncols * nrows, 1);
-            }
         };
         // ---- general path: the reference's decision in fp64 in its own operation order (any k, R, window, count) ----
         // one reciprocal per row where the whole strip sees the full window width (the count is uniform then)
@@ -389,10 +453,15 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
             const double urcd = rcp_nr((double)ucount), uhrcd = 0.5 * urcd;
 #pragma unroll
             for (int i = 0; i < K; i++) {
-                unsigned S, Q, count;
-                window(i, S, Q, count);
+                unsigned S, Q, count = ucount;
+                window(i, S, Q);
                 double rcd = urcd, hrcd = uhrcd;
-                if (!full_cols) { rcd = rcp_nr((double)count); hrcd = 0.5 * rcd; }
+                if (!full_cols) {
+                    const int c = c0 + i;
+                    const int ncols = min(c + r, w - 1) - max(c - l + 1, 0) + 1;
+                    count = (unsigned)max(ncols * nrows, 1);
+                    rcd = rcp_nr((double)count); hrcd = 0.5 * rcd;
+                }
                 const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
                 const double Sd = (double)S, Qd = (double)Q, pxd = (double)px;
                 const bool fa = sauvola_form_dd(Sd, Qd, pxd, rcd, hrcd, kpos, P.km1, P.k2);   // pyx:144-151
@@ -409,54 +478,53 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
                 }
             }
         };
-        if constexpr (!FAST) {
-            general_row();
-        } else if (!(full_cols && RW.ok)) {
-            general_row();           // strips at the left / right image border, or a count without magic numbers
-        } else {
-            // ---- table path: one count for the whole row ------------------------------------------------------------
-            // mean = S / count and Q / count as exact integer quotients (magic-number multiplies, host-checked for
-            // every dividend the window can produce); variance = Q/count - mean^2 as an integer (>= 0 by Cauchy-Schwarz
-            // and floor monotonicity) converted once -- the very value the reference's fp64 subtraction of two integers
-            // yields; mean * (k-1) and mean^2 * k2 from the tables.  What remains of pyx:147-151 is its own sequence:
-            // tmp = px + mean*(k-1); lhs = tmp*tmp; rhs = (mean^2*k2) * variance; two compares.  Bit-exact by
-            // construction: every fp64 operation is the reference's, on the reference's operands.
-            // (k >= 0 here: the launcher sends negative k to the general kernel.)  The form bits of a lane's K pixels are
-            // shifted into one register through the carry: v_addc(bits, bits, form) = 2 bits + form, one instruction per
-            // pixel where select + or take two; pixels run K-1 .. 0 so that bit i is pixel i.
-            auto form_tab = [&](unsigned S, unsigned Q, double pxd, unsigned &bits) {
-                const unsigned mean = __builtin_amdgcn_ubfe(__umulhi(S, RW.ms), (unsigned)RW.ss, 8u);   // <= 255: a table index even in halo lanes
-                const unsigned q = __umulhi(Q, RW.mq) >> RW.sq;
-                const double vard = (double)(q - __umul24(mean, mean));
-                double tkm1, tk2;
-                if constexpr (TABLES) { tkm1 = Tkm1[mean]; tk2 = Tk2[mean]; }
-                else {
-                    const double meand = (double)mean;
-                    tkm1 = __dmul_rn(meand, P.km1);
-                    tk2 = __dmul_rn(__dmul_rn(meand, meand), P.k2);
-                }
-                const double tmp = __dadd_rn(pxd, tkm1);
-                const double lhs = __dmul_rn(tmp, tmp);
-                const double rhs = __dmul_rn(tk2, vard);
-                // two ballots of plain compares OR-ed on the scalar side (the ballot of `a || b` goes through a VGPR bool)
-                const unsigned long long form = __builtin_amdgcn_ballot_w64(tmp <= 0) | __builtin_amdgcn_ballot_w64(lhs <= rhs);
-                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(form) : "vcc");
-            };
+        // ---- table path ----
+        // form <=> Q >= count * T2[mean][px]; the form bits of a lane's K pixels are shifted into one register through
+        // the carry: v_addc(bits, bits, form) = 2 bits + form; pixels run K-1 .. 0 so that bit i is pixel i.
+        auto form_t2 = [&](unsigned S, unsigned Q, unsigned px, unsigned ms, unsigned ss, unsigned cnt, unsigned &bits) {
+            const unsigned mean = __builtin_amdgcn_ubfe(__umulhi(S, ms), ss, 8u);   // <= 255: a table row even in halo lanes
+            const int d = (int)px - (int)mean;
+            int j;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(j) : "v"(d), "v"(dlo1v), "v"(dhi1v));
+            unsigned rowaddr = __umul24(mean, tabW2) + tabC;         // v_mad_u32_u24
+            asm("" : "+v"(rowaddr));                                 // (keeps the compiler from re-associating it into mul + add3)
+            const unsigned addr = ((unsigned)j << 1) + rowaddr;      // v_lshl_add_u32
+            const unsigned T2 = *(lds_u16p)(uintptr_t)addr;
+            const unsigned long long form = __builtin_amdgcn_ballot_w64(Q >= __umul24(cnt, T2));
+            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(form) : "vcc");
+        };
+        auto table_row = [&](auto per_lane) {
+            constexpr bool PER_LANE = decltype(per_lane)::value;
             unsigned bits_a = 0, bits_b = 0;
 #pragma unroll
             for (int i = K - 1; i >= 0; i--) {
-                unsigned S, Q, count;
-                window(i, S, Q, count);
-                const double pxd = (double)((cv[i / 4] >> (8 * (i & 3))) & 0xffu);
-                form_tab(S, Q, pxd, bits_a);
+                unsigned S, Q;
+                window(i, S, Q);
+                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
+                unsigned ms = RW.ms, ss = (unsigned)RW.ss, cnt = ucount, c255 = RW.c255, c65025 = RW.c65025;
+                if constexpr (PER_LANE) {
+                    const u32x4 rec = *(lds_u4p)(uintptr_t)recaddr[i];
+                    ms = rec.x; ss = rec.y; cnt = rec.z;
+                    if constexpr (BOTH) { c255 = __umul24(cnt, 255u); c65025 = __umul24(cnt, 65025u); }
+                }
+                form_t2(S, Q, px, ms, ss, cnt, bits_a);
                 if constexpr (BOTH)       // the window on 255 - p: sums from S, Q and the count (integers below 2^32)
-                    form_tab(RW.c255 - S, (Q + RW.c65025) - 510u * S, 255.0 - pxd, bits_b);
+                    form_t2(c255 - S, (Q + c65025) - 510u * S, 255u - px, ms, ss, cnt, bits_b);
             }
 #pragma unroll
             for (int q = 0; q < KD; q++) {          // bit i -> byte i (0/1)
                 outa[q] = __umul24((bits_a >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
                 if constexpr (BOTH) outb[q] = __umul24((bits_b >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
             }
+        };
+        if constexpr (!TAB) {
+            general_row();
+        } else if (full_cols && RW.ok) {
+            table_row(std::false_type{});
+        } else if (!full_cols && nrows == P.wh && P.colrec_ok) {
+            table_row(std::true_type{});
+        } else {
+            general_row();           // a count without a magic number; border strips while the window is clipped vertically
         }
         // form -> stored value (pyx:153 `0 if formres else 1`, complemented for mrc.py:85's np.invert), columns
         // outside the strip's outputs cleared, set pixels counted
@@ -547,6 +615,58 @@ __global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJo
     }
 }
 
+// LDS byte offset of a __shared__ object (the low half of its flat address)
+template <class T>
+__device__ __forceinline__ unsigned lds_offset(T *p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)p;
+}
+
+// general kernel: one wave per workgroup, one tile per wave, the fp64 decision everywhere
+template <int K, bool MULTI, bool BOTH, int PL = 32>
+__global__ __launch_bounds__(64, (K == 8 ? 4 : 1)) void sauvola_kernel(SauvolaJob job1, const SauvolaJob *jobs,
+                                                     SauvolaParams P) {
+    constexpr int LS = 64 + 2 * PL;
+    __shared__ uint2 EBuf[K * LS];
+    SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
+    const int X0 = blockIdx.x * P.two;
+    const int Y0 = blockIdx.y * P.th;
+    if (X0 >= job.w || Y0 >= job.h) return;
+    sauvola_tile<K, false, BOTH, PL>(job, P, lds_offset(EBuf), 0u, 0u, X0, Y0, (int)threadIdx.x);
+}
+
+// table kernel: NW waves per workgroup share one LDS copy of the decision table (and of the border records); each
+// wave then works on its own tile exactly like the general kernel's single wave (no barrier after the staging).
+// Tiles of a job are numbered strip-major; workgroup b's wave v takes tile b * NW + v.
+template <int K, bool MULTI, bool BOTH, int PL, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void sauvola_tab_kernel(SauvolaJob job1, const SauvolaJob *jobs,
+                                                                   SauvolaParams P) {
+    constexpr int LS = 64 + 2 * PL;
+    __shared__ uint2 EBuf[NW * K * LS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    {
+        typedef const u32x4 __attribute__((address_space(1))) *gc_u4p;
+        const gc_u4p src = (gc_u4p)(uintptr_t)P.tab;
+        u32x4 *dst = (u32x4 *)dyn_lds;
+        const int n16 = P.tab_bytes >> 4;
+        for (int i = threadIdx.x; i < n16; i += 64 * NW) dst[i] = src[i];
+        const gc_u4p rsrc = (gc_u4p)(uintptr_t)P.colrec;
+        u32x4 *rdst = (u32x4 *)(dyn_lds + P.tab_bytes);
+        for (int i = threadIdx.x; i < P.colrec_n; i += 64 * NW) rdst[i] = rsrc[i];
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int tile = blockIdx.x * NW + wave;
+    const int tx = tile % P.strips, ty = tile / P.strips;
+    SauvolaJob job = MULTI ? jobs[blockIdx.z] : job1;
+    const int X0 = tx * P.two;
+    const int Y0 = ty * P.th;
+    if (ty >= P.ytiles || X0 >= job.w || Y0 >= job.h) return;
+    const unsigned tab_lds = lds_offset(dyn_lds);
+    sauvola_tile<K, true, BOTH, PL>(job, P, lds_offset(EBuf) + (unsigned)(wave * K * LS * 8), tab_lds,
+                                    tab_lds + (unsigned)P.tab_bytes, X0, Y0, lane);
+}
+
 // floor(n / c) == mulhi(n, m) >> sh for every 0 <= n <= nmax, with m = ceil(2^(32+sh) / c) < 2^32: true iff
 // (m c - 2^(32+sh)) nmax < 2^(32+sh) (Granlund-Montgomery).  The largest shift whose multiplier fits 32 bits
 // is the most accurate one, so only that one is tried.
@@ -563,30 +683,127 @@ static bool magic_for(unsigned long long c, unsigned long long nmax, unsigned *m
     return false;
 }
 
-// Row tables are a function of the window only: built once per (ww, wh) and kept for the life of the process
-// (a few hundred bytes each).  Returns the device copy, nullptr if it cannot be made.
-static const SauvolaRow *row_table(mrchip_ctx *ctx, int ww, int wh, std::vector<SauvolaRow> *host_copy = nullptr) {
-    struct Entry { int dev, ww, wh; SauvolaRow *d; std::vector<SauvolaRow> h; };
-    static std::vector<Entry> cache;
+// Count tables are a function of the window only: built once per (ww, wh) and kept for the life of the process
+// (a few hundred bytes each): per row count nrows (count = ww * nrows) and, for the full window height, per column
+// count ncols (count = ncols * wh: strips at the left / right image border).
+struct SauvolaCounts {
+    int dev, ww, wh;
+    SauvolaRow *d_rows = nullptr;
+    uint4 *d_cols = nullptr;       // [ww + 1] {ms, ss, count, ok}
+    int cols_ok = 0;
+};
+static const SauvolaCounts *count_tables(mrchip_ctx *ctx, int ww, int wh) {
+    static std::vector<SauvolaCounts *> cache;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    for (auto &e : cache)
-        if (e.dev == ctx->device && e.ww == ww && e.wh == wh) { if (host_copy) *host_copy = e.h; return e.d; }
-    Entry e;
-    e.dev = ctx->device; e.ww = ww; e.wh = wh; e.d = nullptr;
-    e.h.assign(wh + 1, SauvolaRow{});
+    for (auto *e : cache)
+        if (e->dev == ctx->device && e->ww == ww && e->wh == wh) return e;
+    auto *e = new SauvolaCounts;
+    e->dev = ctx->device; e->ww = ww; e->wh = wh;
+    std::vector<SauvolaRow> rows(wh + 1, SauvolaRow{});
     for (int nr = 1; nr <= wh; nr++) {
-        SauvolaRow &r = e.h[nr];
+        SauvolaRow &r = rows[nr];
         const unsigned long long c = (unsigned long long)ww * nr;
         r.c255 = (unsigned)(255ull * c); r.c65025 = (unsigned)(65025ull * c);
-        r.ok = 65025ull * c <= 0xffffffffull && magic_for(c, 255ull * c, &r.ms, &r.ss) &&
-               magic_for(c, 65025ull * c, &r.mq, &r.sq);
+        r.ok = 65026ull * c <= 0xffffffffull && magic_for(c, 255ull * c, &r.ms, &r.ss);
     }
-    if (hipMalloc((void **)&e.d, e.h.size() * sizeof(SauvolaRow)) != hipSuccess) return nullptr;
-    if (hipMemcpy(e.d, e.h.data(), e.h.size() * sizeof(SauvolaRow), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    std::vector<uint4> cols(ww + 1, uint4{0, 0, 1, 0});
+    e->cols_ok = 1;
+    for (int nc = 1; nc <= ww; nc++) {
+        const unsigned long long c = (unsigned long long)nc * wh;
+        unsigned ms = 0; int ss = 0;
+        const bool ok = 65026ull * c <= 0xffffffffull && magic_for(c, 255ull * c, &ms, &ss);
+        cols[nc] = uint4{ms, (unsigned)ss, (unsigned)c, ok ? 1u : 0u};
+        if (!ok) e->cols_ok = 0;
+    }
+    if (hipMalloc((void **)&e->d_rows, rows.size() * sizeof(SauvolaRow)) != hipSuccess ||
+        hipMalloc((void **)&e->d_cols, cols.size() * sizeof(uint4)) != hipSuccess ||
+        hipMemcpy(e->d_rows, rows.data(), rows.size() * sizeof(SauvolaRow), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_cols, cols.data(), cols.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) {
+        delete e;
+        return nullptr;
+    }
     cache.push_back(e);
-    if (host_copy) *host_copy = e.h;
-    return e.d;
+    return e;
+}
+
+// The decision table of one (k, R): built on the device on first use (bisection with the general path's predicate),
+// compacted on the host to the band of d = px - mean whose entries are not constant, kept for the life of the process.
+struct SauvolaTable {
+    int dev; double k, R;
+    unsigned short *d_tab = nullptr;
+    int W = 0, dlo1 = 0, dhi1 = 0, bytes = 0;
+    bool ok = false;
+};
+static const SauvolaTable *decision_table(mrchip_ctx *ctx, double k, double R) {
+    static std::vector<SauvolaTable *> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto *e : cache)
+        if (e->dev == ctx->device && e->k == k && e->R == R) return e;
+    auto *e = new SauvolaTable;
+    e->dev = ctx->device; e->k = k; e->R = R;
+    cache.push_back(e);                      // a failed build is remembered too (ok = false: the general path)
+    if (!(k >= 0)) return e;
+    unsigned short *d_full = nullptr;
+    std::vector<unsigned short> full(65536);
+    hipStream_t st = nullptr;
+    bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                hipMalloc((void **)&d_full, 65536 * 2) == hipSuccess;
+    if (good) {
+        hipLaunchKernelGGL(sauvola_t2_build_kernel, dim3(256), dim3(256), 0, st, d_full, k - 1, k * k / R / R);   // pyx:62
+        good = hipGetLastError() == hipSuccess &&
+               hipMemcpyAsync(full.data(), d_full, 65536 * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (d_full) (void)hipFree(d_full);
+    if (st) (void)hipStreamDestroy(st);
+    if (!good) return e;
+    int dlo = 256, dhi = -256;               // d range of the entries that are not "always" / not "never"
+    for (int m = 0; m < 256; m++)
+        for (int px = 0; px < 256; px++) {
+            const unsigned short t = full[m * 256 + px];
+            if (t != 0) dlo = std::min(dlo, px - m);
+            if (t != 65026) dhi = std::max(dhi, px - m);
+        }
+    if (dlo > 255 || dhi < -255) return e;   // a constant decision: not worth a table
+    e->dlo1 = dlo - 1; e->dhi1 = dhi + 1;
+    e->W = e->dhi1 - e->dlo1 + 1;
+    std::vector<unsigned short> tab((size_t)256 * e->W + 8, 0);
+    for (int m = 0; m < 256; m++)
+        for (int j = 0; j < e->W; j++) {
+            const int d = e->dlo1 + j, px = m + d;
+            unsigned short v = 0;
+            if (j == 0) v = 0;                          // every d below the band: tmp <= 0 for every mean
+            else if (j == e->W - 1) v = 65026;          // every d above it: never
+            else if (px >= 0 && px <= 255) v = full[m * 256 + px];
+            tab[(size_t)m * e->W + j] = v;
+        }
+    e->bytes = (int)((256 * e->W * 2 + 15) & ~15);
+    if (hipMalloc((void **)&e->d_tab, e->bytes) != hipSuccess ||
+        hipMemcpy(e->d_tab, tab.data(), e->bytes, hipMemcpyHostToDevice) != hipSuccess)
+        return e;
+    e->ok = true;
+    return e;
+}
+
+// every (mean, px, var) the kernel can see, table against predicate (see sauvola_t2_selftest_kernel)
+int sauvola_table_selftest(mrchip_ctx *ctx, hipStream_t s, double k, double R, unsigned long long *d_bad_tested, int *table_bytes) {
+    const SauvolaTable *t = decision_table(ctx, k, R);
+    if (!t || !t->ok) { set_error("sauvola: no decision table for k = %g, R = %g", k, R); return MRCHIP_E_UNSUPPORTED; }
+    HIP_TRY(hipMemsetAsync(d_bad_tested, 0, 16, s));
+    hipLaunchKernelGGL(sauvola_t2_selftest_kernel, dim3(256), dim3(256), 0, s, t->d_tab, t->W, t->dlo1, t->dhi1, k - 1,
+                       k * k / R / R, d_bad_tested, d_bad_tested + 1);
+    HIP_TRY(hipGetLastError());
+    if (table_bytes) *table_bytes = t->bytes;
+    return 0;
+}
+
+// one-time opt-in of a kernel to more dynamic LDS than the default limit
+template <class F>
+static int allow_dynamic_lds(F *kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
 }
 
 template <int K>
@@ -612,9 +829,8 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     // measured flat between 32 and 512 rows per tile on 64-page batches; 1024 starves the chip
     int th = 256;
     while (th > 32 && (long long)strips * cdiv(maxh, th) * njobs < 8192) th >>= 1;
-    if (const char *e = getenv("MRCHIP_SAUVOLA_TH")) { int v = atoi(e); if (v >= 8) th = v; }   // tuning knob
     P.th = th;
-    dim3 grid(strips, cdiv(maxh, th), njobs);
+    P.strips = strips; P.ytiles = cdiv(maxh, th);
     const char *nm = (njobs == 1 && !d_jobs) ? "sauvola" : (h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola");
     const bool single = njobs == 1 && !d_jobs;
     const bool both = h_jobs[0].dst_inv != nullptr;
@@ -622,29 +838,53 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
         if ((h_jobs[i].dst_inv != nullptr) != both) { set_error("sauvola: jobs with and without a second polarity in one launch"); return MRCHIP_E_ARG; }
     // slack lanes of the LDS prefix rows: 8 when K * 8 columns cover half the window (the pipeline's windows), else 32
     const bool small_pl = K <= 8 && P.l + K <= K * 8;
-#define SAUVOLA_LAUNCH(MULTI_, FAST_, BOTH_)                                                                     \
+    const int sel = (single ? 0 : 2) | (both ? 1 : 0);
+    if constexpr (K <= 8) {
+        // table kernel: NW waves share one LDS copy of the table -- 16 waves (a CU's worth at 4 per SIMD) for the
+        // 8-column page kernel, 8 for the 4-column kernel of the hOCR boxes (several workgroups per CU)
+        constexpr int NW = K == 8 ? 16 : 8, WPE = K == 8 ? 4 : 6;
+        const int dyn = P.tab_bytes + 16 * P.colrec_n;
+        const int stat = NW * K * (64 + 2 * (small_pl ? 8 : 32)) * 8;
+        if (P.tab && (K == 4 || small_pl) && stat + dyn <= 160 * 1024) {
+            dim3 grid(cdiv(P.strips * P.ytiles, NW), 1, njobs);
+#define SAUVOLA_TAB_LAUNCH(MULTI_, BOTH_, PL_)                                                                         \
+    do {                                                                                                               \
+        auto *kern = sauvola_tab_kernel<K, MULTI_, BOTH_, PL_, NW, WPE>;                                               \
+        static int allowed = 0;                                                                                        \
+        if (allowed < dyn) { TRY(allow_dynamic_lds(kern, dyn)); allowed = dyn; }                                       \
+        LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL(kern, grid, dim3(64 * NW), dyn, s, h_jobs[0], d_jobs, P));    \
+    } while (0)
+#define SAUVOLA_TAB_LAUNCH_PL(MULTI_, BOTH_)                                                                           \
+    do {                                                                                                               \
+        if (small_pl) SAUVOLA_TAB_LAUNCH(MULTI_, BOTH_, 8);                                                            \
+        else if constexpr (K == 4) SAUVOLA_TAB_LAUNCH(MULTI_, BOTH_, 32);                                              \
+    } while (0)
+            switch (sel) {
+                case 0: SAUVOLA_TAB_LAUNCH_PL(false, false); break;
+                case 1: SAUVOLA_TAB_LAUNCH_PL(false, true); break;
+                case 2: SAUVOLA_TAB_LAUNCH_PL(true, false); break;
+                default: SAUVOLA_TAB_LAUNCH_PL(true, true); break;
+            }
+#undef SAUVOLA_TAB_LAUNCH_PL
+#undef SAUVOLA_TAB_LAUNCH
+            return 0;
+        }
+    }
+    dim3 grid(strips, cdiv(maxh, th), njobs);
+#define SAUVOLA_LAUNCH(MULTI_, BOTH_)                                                                            \
     do {                                                                                                         \
         if (small_pl && K <= 8)                                                                                  \
-            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_, (K <= 8 ? 8 : 32)>), grid, \
+            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, BOTH_, (K <= 8 ? 8 : 32)>), grid, \
                                                              dim3(64), 0, s, h_jobs[0], d_jobs, P));              \
         else                                                                                                     \
-            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, FAST_, BOTH_, 32>), grid, dim3(64), 0, s, \
+            LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL((sauvola_kernel<K, MULTI_, BOTH_, 32>), grid, dim3(64), 0, s, \
                                                              h_jobs[0], d_jobs, P));                              \
     } while (0)
-    // the integer-quotient decision pays on the page kernel (one polarity: 38 -> 30 VALU instructions per pixel, 128 blurred
-    // pages 2.48 -> 2.33 ms, the noisy c3gray batch unchanged); the two-polarity box kernel measured 4 % slower with it
-    // (same-box A/B), so the boxes keep the fp64 quotients unless MRCHIP_SAUVOLA_FAST=2 asks otherwise
-    const bool fast = P.fast && (!both || P.fast >= 2);
-    const int sel = (single ? 0 : 4) | (fast ? 2 : 0) | (both ? 1 : 0);
     switch (sel) {
-        case 0: SAUVOLA_LAUNCH(false, false, false); break;
-        case 1: SAUVOLA_LAUNCH(false, false, true); break;
-        case 2: SAUVOLA_LAUNCH(false, true, false); break;
-        case 3: SAUVOLA_LAUNCH(false, true, true); break;
-        case 4: SAUVOLA_LAUNCH(true, false, false); break;
-        case 5: SAUVOLA_LAUNCH(true, false, true); break;
-        case 6: SAUVOLA_LAUNCH(true, true, false); break;
-        default: SAUVOLA_LAUNCH(true, true, true); break;
+        case 0: SAUVOLA_LAUNCH(false, false); break;
+        case 1: SAUVOLA_LAUNCH(false, true); break;
+        case 2: SAUVOLA_LAUNCH(true, false); break;
+        default: SAUVOLA_LAUNCH(true, true); break;
     }
 #undef SAUVOLA_LAUNCH
     return 0;
@@ -680,11 +920,10 @@ int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_b
 
 // columns per lane of the kernel a launch takes
 static int sauvola_columns_per_lane(int maxw, int maxh, int ww) {
-    static const int force_k = getenv("MRCHIP_SAUVOLA_K") ? atoi(getenv("MRCHIP_SAUVOLA_K")) : 0;   // tuning knob
     // 8 columns per lane halve the strip halo (452 of 512 columns are outputs instead of 200 of 256) at the
     // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops
     const bool page_like = maxw >= 1024 && maxh >= 256;
-    if (ww <= 120 && force_k != 8 && !(page_like && force_k != 4)) return 4;
+    if (ww <= 120 && !page_like) return 4;
     return ww <= 360 ? 8 : 16;
 }
 
@@ -704,23 +943,25 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
         set_error("sauvola: window %dx%d exceeds the supported area (<= 65792 = 256x257)", ww, wh);
         return MRCHIP_E_UNSUPPORTED;
     }
-    SauvolaParams P;
+    SauvolaParams P = {};
     P.ww = ww; P.wh = wh;
     P.l = (ww + 1) / 2; P.r = ww / 2; P.o = (wh + 1) / 2; P.u = wh / 2;
     P.k = k; P.km1 = k - 1; P.k2 = k * k / R / R;     // pyx:62
     P.flags = flags;
-    // Table-driven decision (sauvola_kernel, FAST): exact integer quotients by the row's uniform count + LDS tables of
-    // the mean-dependent fp64 products; every fp64 operation left is the reference's own, so the result is bit-exact by
-    // construction for any k and R.  Rows whose count has no 32-bit magic numbers, and strips at the left / right image
-    // border (per-lane counts), take the general fp64 path inside the same kernel.  MRCHIP_SAUVOLA_FAST=0 forces the
-    // general path everywhere (the parity tests run both).
-    // (Round 2 first tried a guarded fp32 comparison here: bit-exact with its fp64 arbiter, but no fewer instructions
-    // than the fp64 path -- DESIGN.md 5; it is gone, git history has it.)
+    const SauvolaCounts *ct = count_tables(ctx, ww, wh);
+    if (!ct) { set_error("sauvola: cannot allocate the count tables"); return MRCHIP_E_NOMEM; }
+    P.rows = ct->d_rows;
+    // Table-driven decision (sauvola_tab_kernel) for k >= 0 wherever the count has a magic number; everything else --
+    // k < 0, a (k, R) whose band does not fit the LDS, windows too wide for the 4- / 8-column strips -- and the whole
+    // launch under MRCHIP_SAUVOLA_FAST=0 (the parity tests run both) takes the reference's fp64 sequence.
     const char *fast_env = getenv("MRCHIP_SAUVOLA_FAST");
-    const int no_fast = fast_env && atoi(fast_env) == 0;
-    P.rows = row_table(ctx, ww, wh);
-    if (!P.rows) { set_error("sauvola: cannot allocate the row table"); return MRCHIP_E_NOMEM; }
-    P.fast = (!no_fast && k >= 0) ? ((fast_env && atoi(fast_env) >= 2) ? 2 : 1) : 0;
+    if (!(fast_env && atoi(fast_env) == 0) && k >= 0) {
+        const SauvolaTable *t = decision_table(ctx, k, R);
+        if (t && t->ok) {
+            P.tab = t->d_tab; P.tab_bytes = t->bytes; P.tabW = t->W; P.dlo1 = t->dlo1; P.dhi1 = t->dhi1;
+            P.colrec = ct->d_cols; P.colrec_n = ww + 1; P.colrec_ok = ct->cols_ok;
+        }
+    }
     int maxw = 0, maxh = 0;
     double alg = 0;
     for (int i = 0; i < njobs; i++) {

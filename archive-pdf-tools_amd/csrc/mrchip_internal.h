@@ -326,6 +326,8 @@ int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int 
                          size_t bits_stride, int npages, bool bits_ready = false);
 size_t denoise_scratch_bytes(int w, int h);
 int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
+// d_bad_tested[0] += mismatching, [1] += tested (mean, px, var) triples of the decision table of (k, R)
+int sauvola_table_selftest(mrchip_ctx *ctx, hipStream_t s, double k, double R, unsigned long long *d_bad_tested, int *table_bytes);
 int optimise_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
 // 1 bpp MSB-first rows of (w+7)/8 bytes; page i at out + i*ostride
 int launch_pack_msb(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, uint8_t *out, size_t ostride, int npages);

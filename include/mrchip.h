@@ -226,6 +226,13 @@ int mrchip_batch_device_ptrs(mrchip_batch *b, int page, void **img, void **mask,
  * truncating integer divisions): every divisor 1..65792, the dividends around each multiple.
  * *mismatches = number of (dividend, divisor) pairs whose quotient differs from integer division. */
 int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *mismatches);
+/* Device self-test of the table-driven decision of mrchip_sauvola_u8 for one (k >= 0, R) (cython/sauvola.pyx:62,
+ * 143-153): for every integer mean 0..255, pixel 0..255 and variance 0..255 mean + 254 - mean^2 (every value a
+ * window of 8-bit pixels can produce) the table's answer `variance + mean^2 >= T2[mean][pixel]` against the
+ * reference's fp64 sequence.  *tested = triples compared, *table_bytes = size of the table (NULL: not wanted).
+ * MRCHIP_E_UNSUPPORTED if this (k, R) has no table (the launch then uses the fp64 sequence for every pixel). */
+int mrchip_selftest_sauvola_table(mrchip_ctx *ctx, double k, double R, long long *mismatches, long long *tested,
+                                  int *table_bytes);
 /* Same for mrchip_optimise's `val / cnt` (cython/optimiser.pyx:261-269): every count 1..5120 (n_size <= 32)
  * against every value 0..255*count. */
 int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches);

@@ -113,26 +113,61 @@ def test_fp64_quotients_equal_integer_division_for_every_divisor():
     assert bad.value == 0
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '2'])
-def test_quotient_paths_agree_with_the_oracle(mode, monkeypatch):
-    """The decision has two forms of its truncating quotients: fp64 (floor of an fma with a refined reciprocal, any
-    count) and integer magic-number multiplies by the row's uniform count (default for one polarity; MRCHIP_SAUVOLA_FAST=2
-    also for the two-polarity hOCR-box launch, =0 nowhere).  Everything after the quotients is the reference's own fp64
-    sequence either way: all three settings must equal the oracle on pages (borders = per-lane counts, top / bottom =
-    changing row counts) and on the box masks."""
+@pytest.mark.parametrize('k,R', [(0.34, 128.0), (0.1, 128.0), (0.0, 128.0), (0.2, 128.0), (0.5, 128.0), (0.34, 64.0)])
+def test_decision_table_equals_the_fp64_sequence_for_every_mean_pixel_variance(k, R):
+    """Device self-test of the table-driven decision: for every integer mean, pixel and reachable variance (7.1e8
+    triples per (k, R)) `var + mean^2 >= T2[mean][px]`, read with the kernel's index arithmetic from the table the
+    kernel stages into LDS, equals the reference's fp64 sequence (sauvola.pyx:143-153) as the general path runs it."""
+    import ctypes as C
+    from mrchip import _lib
+    bad, tested, nbytes = C.c_longlong(-1), C.c_longlong(0), C.c_int(0)
+    _lib.check(_lib.load().mrchip_selftest_sauvola_table(_lib.default_context().handle, k, R, C.byref(bad), C.byref(tested),
+                                                         C.byref(nbytes)))
+    assert bad.value == 0, (k, R, bad.value)
+    assert tested.value == 256 * sum(min(65025, 255 * m + 254) - m * m + 1 for m in range(256))
+    assert 0 < nbytes.value <= 128 * 1024
+
+
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_decision_paths_agree_with_the_oracle(mode, monkeypatch):
+    """The decision has two forms: the reference's fp64 sequence on exact quotients (any k, any count;
+    MRCHIP_SAUVOLA_FAST=0 everywhere) and, by default for k >= 0, `Q >= count * T2[mean][px]` with the integer mean from
+    a magic-number multiply -- scalar operands where a strip sees the full window width, per-column records at the left
+    / right border, the fp64 sequence where the window is clipped vertically on border strips or the count has no
+    magic number.  Both settings must equal the oracle on pages (borders = per-lane counts, top / bottom = changing row
+    counts), on images narrower / shorter than the window, and on the box masks (two polarities)."""
     from mrchip import mrc
     monkeypatch.setenv('MRCHIP_SAUVOLA_FAST', mode)
     rng = np.random.RandomState(5 + int(mode))
     for (h, w, ww, wh, k) in [(260, 1300, 51, 51, 0.34), (90, 520, 51, 51, 0.1), (300, 700, 31, 75, 0.34), (64, 2000, 91, 91, 0.5),
-                              (40, 300, 51, 51, 0.0)]:
+                              (40, 300, 51, 51, 0.0), (300, 1100, 101, 101, 0.34), (70, 40, 51, 51, 0.34), (600, 1500, 51, 51, 0.2),
+                              (120, 1030, 101, 101, 0.1), (33, 2100, 25, 25, 0.34)]:
         for img in (rng.randint(0, 256, (h, w)).astype(np.uint8), np.clip(rng.normal(120, 2.5, (h, w)), 0, 255).astype(np.uint8),
-                    synth.synth_page(w, h, 1, seed=h + w + 1, noise_sigma=4.0, line_div=max(2, h // 30))[0]):
+                    synth.synth_page(w, h, 1, seed=h + w + 1, noise_sigma=4.0, line_div=max(2, h // 30))[0],
+                    (rng.randint(0, 2, (h, w)) * 255).astype(np.uint8)):
             got, exp = run_gpu(img, ww, wh, k), run_cpu(img, ww, wh, k)
             assert np.array_equal(got, exp), (mode, h, w, ww, wh, k, int((got != exp).sum()))
     # the two-polarity launch: create_hocr_mask against the oracle
-    img, hocr = synth.synth_page(900, 700, 1, seed=77, noise_sigma=5.0, line_div=14)
-    m_gpu = np.zeros(img.shape, dtype=np.bool_)
-    m_cpu = np.zeros(img.shape, dtype=np.bool_)
-    mrc.create_hocr_mask(img, m_gpu, hocr)
-    O.create_hocr_mask(img, m_cpu, mrc.hocr_boxes(hocr, 900, 700), None)
-    assert np.array_equal(m_gpu, m_cpu), (mode, int((m_gpu != m_cpu).sum()))
+    for (pw, ph, seed) in [(900, 700, 77), (2300, 900, 78)]:
+        img, hocr = synth.synth_page(pw, ph, 1, seed=seed, noise_sigma=5.0, line_div=14)
+        m_gpu = np.zeros(img.shape, dtype=np.bool_)
+        m_cpu = np.zeros(img.shape, dtype=np.bool_)
+        mrc.create_hocr_mask(img, m_gpu, hocr)
+        O.create_hocr_mask(img, m_cpu, mrc.hocr_boxes(hocr, pw, ph), None)
+        assert np.array_equal(m_gpu, m_cpu), (mode, int((m_gpu != m_cpu).sum()))
+
+
+def test_saturated_and_two_level_images():
+    """variance 0 / tmp <= 0 boundary and the extreme variances: constant, two-level (0 / 255 halves, stripes, checker),
+    saturated borders -- the corners of the decision table."""
+    h, w = 200, 1200
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = [np.full((h, w), v, np.uint8) for v in (0, 1, 2, 127, 128, 254, 255)]
+    imgs += [np.where(xx < w // 2, 0, 255).astype(np.uint8), np.where((xx // 7 + yy // 5) % 2 == 0, 0, 255).astype(np.uint8),
+             np.where(xx % 2 == 0, 0, 255).astype(np.uint8), np.where(yy % 3 == 0, 255, 0).astype(np.uint8),
+             np.where((xx < 40) | (xx >= w - 40) | (yy < 40) | (yy >= h - 40), 0, 230).astype(np.uint8),
+             np.where((xx - 600) ** 2 + (yy - 100) ** 2 < 70 ** 2, 255, 3).astype(np.uint8)]
+    for k in (0.34, 0.1):
+        for i, img in enumerate(imgs):
+            got, exp = run_gpu(img, 51, 51, k), run_cpu(img, 51, 51, k)
+            assert np.array_equal(got, exp), (k, i, int((got != exp).sum()))

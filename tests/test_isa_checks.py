@@ -40,8 +40,10 @@ def _scratch_of(listing, key):
 
 def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
     lst = _listing(tmp_path, 'k_sauvola')
-    for key in ('sauvola_kernelILi8ELb1ELb1ELb0', 'sauvola_kernelILi4ELb1ELb1ELb1', 'sauvola_kernelILi8ELb0ELb0ELb0',
-                'sauvola_kernelILi16ELb1ELb0ELb0'):
+    # the table kernels of pages (8 columns, 16 waves) and hOCR boxes (4 columns, two polarities), the fp64 kernels
+    for key in ('sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16', 'sauvola_tab_kernelILi4ELb1ELb1ELi8ELi8', 'sauvola_tab_kernelILi4ELb1ELb1ELi32ELi8',
+                'sauvola_tab_kernelILi8ELb0ELb0ELi8ELi16', 'sauvola_kernelILi8ELb1ELb0ELi8E', 'sauvola_kernelILi4ELb1ELb1ELi32E',
+                'sauvola_kernelILi16ELb1ELb0ELi32E'):
         rc, out = _scan(lst, key)
         assert rc == 0, (key, out[-1500:])
         assert _scratch_of(lst, key) == 0, key
