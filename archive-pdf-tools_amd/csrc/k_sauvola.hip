@@ -481,7 +481,9 @@ __device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const Sauvol
         // ---- table path ----
         // form <=> Q >= count * T2[mean][px]; the form bits of a lane's K pixels are shifted into one register through
         // the carry: v_addc(bits, bits, form) = 2 bits + form; pixels run K-1 .. 0 so that bit i is pixel i.
-        auto form_t2 = [&](unsigned S, unsigned Q, unsigned px, unsigned ms, unsigned ss, unsigned cnt, unsigned &bits) {
+        // Three phases so that the LDS round trips overlap: every window end first, then every table entry, then the
+        // compares (a pixel at a time the row is a chain of 2 x 8 dependent LDS latencies).
+        auto t2_entry = [&](unsigned S, unsigned px, unsigned ms, unsigned ss) {
             const unsigned mean = __builtin_amdgcn_ubfe(__umulhi(S, ms), ss, 8u);   // <= 255: a table row even in halo lanes
             const int d = (int)px - (int)mean;
             int j;
@@ -489,27 +491,37 @@ __device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const Sauvol
             unsigned rowaddr = __umul24(mean, tabW2) + tabC;         // v_mad_u32_u24
             asm("" : "+v"(rowaddr));                                 // (keeps the compiler from re-associating it into mul + add3)
             const unsigned addr = ((unsigned)j << 1) + rowaddr;      // v_lshl_add_u32
-            const unsigned T2 = *(lds_u16p)(uintptr_t)addr;
-            const unsigned long long form = __builtin_amdgcn_ballot_w64(Q >= __umul24(cnt, T2));
-            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(form) : "vcc");
+            return (unsigned)*(lds_u16p)(uintptr_t)addr;
         };
         auto table_row = [&](auto per_lane) {
             constexpr bool PER_LANE = decltype(per_lane)::value;
+            unsigned Sv[K], Qv[K], Ta[K], Tb[K], cntv[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) window(i, Sv[i], Qv[i]);
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
+                unsigned ms = RW.ms, ss = (unsigned)RW.ss, c255 = RW.c255;
+                cntv[i] = ucount;
+                if constexpr (PER_LANE) {
+                    const u32x4 rec = *(lds_u4p)(uintptr_t)recaddr[i];
+                    ms = rec.x; ss = rec.y; cntv[i] = rec.z;
+                    if constexpr (BOTH) c255 = __umul24(cntv[i], 255u);
+                }
+                Ta[i] = t2_entry(Sv[i], px, ms, ss);
+                if constexpr (BOTH) Tb[i] = t2_entry(c255 - Sv[i], 255u - px, ms, ss);   // the window on 255 - p (mrc.py:224, 235)
+            }
             unsigned bits_a = 0, bits_b = 0;
 #pragma unroll
             for (int i = K - 1; i >= 0; i--) {
-                unsigned S, Q;
-                window(i, S, Q);
-                const unsigned px = (cv[i / 4] >> (8 * (i & 3))) & 0xffu;
-                unsigned ms = RW.ms, ss = (unsigned)RW.ss, cnt = ucount, c255 = RW.c255, c65025 = RW.c65025;
-                if constexpr (PER_LANE) {
-                    const u32x4 rec = *(lds_u4p)(uintptr_t)recaddr[i];
-                    ms = rec.x; ss = rec.y; cnt = rec.z;
-                    if constexpr (BOTH) { c255 = __umul24(cnt, 255u); c65025 = __umul24(cnt, 65025u); }
+                const unsigned long long fa = __builtin_amdgcn_ballot_w64(Qv[i] >= __umul24(cntv[i], Ta[i]));
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits_a) : "s"(fa) : "vcc");
+                if constexpr (BOTH) {       // sum((255-p)^2) = 65025 n - 510 S + Q (an integer below 2^32)
+                    const unsigned c65025 = PER_LANE ? __umul24(cntv[i], 65025u) : RW.c65025;
+                    const unsigned Q2 = (Qv[i] + c65025) - 510u * Sv[i];
+                    const unsigned long long fb = __builtin_amdgcn_ballot_w64(Q2 >= __umul24(cntv[i], Tb[i]));
+                    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits_b) : "s"(fb) : "vcc");
                 }
-                form_t2(S, Q, px, ms, ss, cnt, bits_a);
-                if constexpr (BOTH)       // the window on 255 - p: sums from S, Q and the count (integers below 2^32)
-                    form_t2(c255 - S, (Q + c65025) - 510u * S, 255u - px, ms, ss, cnt, bits_b);
             }
 #pragma unroll
             for (int q = 0; q < KD; q++) {          // bit i -> byte i (0/1)
@@ -823,12 +835,22 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
         set_error("sauvola: window width %d too large for the %d-column strip", P.ww, CW);
         return MRCHIP_E_UNSUPPORTED;
     }
-    // rows per tile: tall tiles amortise the (wh-1)-row warm-up; shrink only while the launch
-    // would leave the chip short of waves
+    // Rows per tile.  Tall tiles amortise the (wh-1)-row warm-up, but the launch runs in rounds of `slots` resident waves
+    // and a last round that is a third full costs a whole one (128 pages 4000x3000 at 256 rows: 13 824 tiles on 4 096
+    // slots = 3.4 rounds paid as 4): take the number of equal tile rows whose rounds x (rows + warm-up) is smallest.
     int strips = cdiv(maxw, P.two);
-    // measured flat between 32 and 512 rows per tile on 64-page batches; 1024 starves the chip
     int th = 256;
-    while (th > 32 && (long long)strips * cdiv(maxh, th) * njobs < 8192) th >>= 1;
+    {
+        const long long slots = (long long)(ctx->cus > 0 ? ctx->cus : 256) * (K >= 8 ? 16 : 24);    // resident waves
+        double best = 1e30;
+        for (int yt = 1; yt <= cdiv(maxh, 32); yt++) {
+            const int t = std::max(32, cdiv(maxh, yt));
+            if (t > 1024 && yt < cdiv(maxh, 32)) continue;        // very long tiles leave no slack for uneven progress
+            const long long tiles = (long long)strips * cdiv(maxh, t) * njobs;
+            const double cost = (double)cdiv((int)std::min<long long>(tiles, 1 << 30), (int)slots) * (t + 0.5 * P.wh);
+            if (cost < best * 0.999) { best = cost; th = t; }
+        }
+    }
     P.th = th;
     P.strips = strips; P.ytiles = cdiv(maxh, th);
     const char *nm = (njobs == 1 && !d_jobs) ? "sauvola" : (h_jobs[0].dst_inv ? "sauvola_boxes" : "sauvola");
