@@ -529,7 +529,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     TRY(box_decisions_commit(b, 1));      // mrc.py:240-266 on top: mask = page threshold | box thresholds
     b->commit_bits = false;
     if (denoise_fast)
-        TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N, fuse_bits));  // :388
+        TRY(launch_denoise_batch(ctx, s, b->mask.pl, w, h, 4, 2, b->dn_bits.as<unsigned>(), b->dn_stride, N, fuse_bits, true));  // :388
     b->state = 4;
     b->packed_valid = 0;
     // the denoiser's bit rows are the final mask when its bit-sliced path ran (launch_denoise_batch)
@@ -677,22 +677,14 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
             j.mask = b->mask.pl.page(i); j.mpitch = b->mask.pl.pitch;
             j.mbits = b->bits_valid ? b->dn_bits.as<unsigned>() + (size_t)i * b->dn_stride : nullptr;
             j.mwpr = cdiv(w, 32);
+            j.rowflags = b->bits_valid ? reinterpret_cast<const uint8_t *>(b->dn_bits.as<unsigned>() + (size_t)i * b->dn_stride) +
+                                             denoise_rowflags_offset(w, h) : nullptr;
             j.img = b->img.pl.page(i); j.ipitch = b->img.pl.pitch;
             j.out = b->layer[Lr].pl.page(i); j.opitch = b->layer[Lr].pl.pitch;
             j.w = w; j.h = h;
             j.n = Lr ? 10 : 3;                                           // mrc.py:413/415, 447/449
             j.invert = Lr ? 1 : 0;                                       // mask_inv, mrc.py:439
             nmax = std::max(nmax, j.n);
-        }
-    }
-    if (const char *e = getenv("MRCHIP_OPT_ORDER")) {          // experiment: fg / bg jobs interleaved in blocks of `e`
-        const int blk = atoi(e);
-        if (blk > 0 && do_fg && do_bg && N % blk == 0) {
-            std::vector<OptJob> tmp(hj, hj + nj);
-            int k = 0;
-            for (int i0 = 0; i0 < N; i0 += blk)
-                for (int Lr = 0; Lr < 2; Lr++)
-                    for (int i = i0; i < i0 + blk; i++) hj[k++] = tmp[Lr * N + i];
         }
     }
     TRY(launch_optimise_jobs(ctx, s, hj, dj, nj, w, h, c, nmax, &b->opt_mail));      // (uploads the job records)

@@ -102,26 +102,34 @@ int launch_pack_msb(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, ui
 
 __device__ __forceinline__ unsigned spread_nibble(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
+// rowflags (optional): byte y of a page = 1 when row y of the finished mask has a set pixel (pre-zeroed by the launcher);
+// the band walkers of optimise cut the bg layer at the rows without ink (k_optimise.hip, OptBand)
 __global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned *bits, int wpr, size_t bstride, uint8_t *mask,
-                                                          int pitch, size_t mstride, int w, int h) {
+                                                          int pitch, size_t mstride, int w, int h, uint8_t *rowflags,
+                                                          size_t rfstride) {
     const int y = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= wpr) return;
-    mask += (size_t)blockIdx.z * mstride;
-    bits += (size_t)blockIdx.z * bstride;
-    const unsigned word = bits[(size_t)y * wpr + j];
-    uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
-    if (j * 32 + 32 <= w) {
-        uint4 a, b;
-        a.x = spread_nibble(word & 0xF); a.y = spread_nibble((word >> 4) & 0xF);
-        a.z = spread_nibble((word >> 8) & 0xF); a.w = spread_nibble((word >> 12) & 0xF);
-        b.x = spread_nibble((word >> 16) & 0xF); b.y = spread_nibble((word >> 20) & 0xF);
-        b.z = spread_nibble((word >> 24) & 0xF); b.w = spread_nibble(word >> 28);
-        reinterpret_cast<uint4 *>(row)[0] = a;
-        reinterpret_cast<uint4 *>(row)[1] = b;
-    } else {
-        for (int i = 0; j * 32 + i < w; i++) row[i] = (word >> i) & 1u;
+    unsigned word = 0;
+    if (j < wpr) {
+        mask += (size_t)blockIdx.z * mstride;
+        bits += (size_t)blockIdx.z * bstride;
+        word = bits[(size_t)y * wpr + j];
+        if (j == wpr - 1 && (w & 31)) word &= (1u << (w & 31)) - 1u;
+        uint8_t *row = mask + (size_t)y * pitch + (size_t)j * 32;
+        if (j * 32 + 32 <= w) {
+            uint4 a, b;
+            a.x = spread_nibble(word & 0xF); a.y = spread_nibble((word >> 4) & 0xF);
+            a.z = spread_nibble((word >> 8) & 0xF); a.w = spread_nibble((word >> 12) & 0xF);
+            b.x = spread_nibble((word >> 16) & 0xF); b.y = spread_nibble((word >> 20) & 0xF);
+            b.z = spread_nibble((word >> 24) & 0xF); b.w = spread_nibble(word >> 28);
+            reinterpret_cast<uint4 *>(row)[0] = a;
+            reinterpret_cast<uint4 *>(row)[1] = b;
+        } else {
+            for (int i = 0; j * 32 + i < w; i++) row[i] = (word >> i) & 1u;
+        }
     }
+    if (rowflags && __any(word != 0u) && (threadIdx.x & 63) == 0)         // one store per wave with a set pixel (same value: no race)
+        rowflags[(size_t)blockIdx.z * rfstride + y] = 1;
 }
 
 // ---- bit-sliced sequential solve (n = 2, mincnt = 4) --------------------------
@@ -494,12 +502,14 @@ static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, s
     return 0;
 }
 
-size_t denoise_scratch_bytes(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) * 2 + 256; }
+// per page: final bit rows | original bit rows | 256 bytes | one flag byte per row ("the finished row has a set pixel")
+size_t denoise_rowflags_offset(int w, int h) { return (size_t)cdiv(w, 32) * h * sizeof(unsigned) * 2 + 256; }
+size_t denoise_scratch_bytes(int w, int h) { return denoise_rowflags_offset(w, h) + (size_t)round_up(h, 256); }
 
 // bits_ready: the original 1-bpp rows (second half of a page's scratch) already hold the mask -- the Sauvola page
 // launch and the hOCR commit wrote them alongside the bytes -- so `pack` is not run
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
-                         size_t bits_stride, int npages, bool bits_ready) {
+                         size_t bits_stride, int npages, bool bits_ready, bool want_rowflags) {
     if (n < 0 || mincnt < 0) { set_error("denoise: negative parameter"); return MRCHIP_E_ARG; }
     if (w <= 2 * n || h <= 2 * n) return 0;      // empty inner rectangle: nothing changes
     const int wpr = cdiv(w, 32);
@@ -514,9 +524,11 @@ int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int 
         else if (wpr <= 128) TRY(launch_seq<2>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else if (wpr <= 256) TRY(launch_seq<4>(ctx, s, bits, wpr, bits_stride, w, h, npages));
         else TRY(launch_seq<8>(ctx, s, bits, wpr, bits_stride, w, h, npages));
+        uint8_t *rf = want_rowflags ? reinterpret_cast<uint8_t *>(bits) + denoise_rowflags_offset(w, h) : nullptr;
+        if (rf) HIP_TRY(hipMemset2DAsync(rf, bits_stride * 4, 0, (size_t)h, npages, s));
         LAUNCH(ctx, s, "denoise_unpack", 1.0 * w * h * npages,
                hipLaunchKernelGGL(unpack_bits_kernel, grid, dim3(256), 0, s, bits, wpr, bits_stride, mask.p, pitch,
-                                  mask.stride, w, h));
+                                  mask.stride, w, h, rf, bits_stride * 4));
         return 0;
     }
   for (int pgi = 0; pgi < npages; pgi++) {

@@ -403,9 +403,20 @@ __device__ __forceinline__ void mail_store(u32x4 *p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
+// ---- bands of rows -------------------------------------------------------------------------------------------
+// Only unselected pixels (mask == 0) are rewritten (pyx:195, 261-269); a row without one is a copy of the image row, and
+// after n such rows in a row the state a later row depends on -- the vertical FIR sums over image rows [y-n, y+n) and
+// the IIR sums over OUTPUT rows [y-n, y) -- is a function of the inputs alone (those output rows ARE image rows).  So
+// maximal runs of rows that are separated by >= n rows without an unselected pixel ("bands") are independent jobs:
+// a band [y0, y1) rebuilds its sums from image rows [y0-1-n, y0+n-1) and walks its rows exactly like a whole page;
+// everything between bands is copied.  For the bg layer of a text page (selected = everything but the ink, n = 10)
+// that is ~26 bands of ~47 rows instead of one chain of 3000; a layer without such gaps (fg: selected = the ink) is one
+// band = the whole page.  A band job also copies the rows [c0, y0) in front of it and [y1, c1) behind it.
+struct OptBand { int job, c0, y0, y1, c1, pad_[3]; };
+
 template <int C, int NH, int NCT, bool DB, bool MB, bool STRIP = false>
 __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned char *smem, const StripInfo SI = StripInfo{1, 0, nullptr, 0, nullptr},
-                                                     int job_index = 0, int strip = 0) {
+                                                     int job_index = 0, int strip = 0, const OptBand *band = nullptr, bool zero_lds = true) {
     constexpr int P = 4;
     constexpr int EW = (C == 3) ? 2 : 1;          // dwords per entry
     constexpr int ND = P * C / 4;                 // dwords of pixel bytes per thread-row
@@ -443,9 +454,13 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int nelem = nent + nent / P + 1;
     unsigned *firA0 = reinterpret_cast<unsigned *>(smem);
     unsigned *iirA0 = firA0 + (size_t)nelem * EW;
-    for (int i = t; i < (DB ? 4 : 2) * nelem * EW; i += T) firA0[i] = 0;
+    // (a workgroup that walks several bands zeroes once: publishing never touches the pad entries left and right of the
+    // image; the barrier also separates the previous band's last LDS reads from this band's first publish)
+    if (zero_lds)
+        for (int i = t; i < (DB ? 4 : 2) * nelem * EW; i += T) firA0[i] = 0;
     __syncthreads();
     unsigned *firA = firA0, *iirA = iirA0;
+    const int yb0 = band ? band->y0 : 0, yb1 = band ? band->y1 : h;          // the rows this call computes
     // column c -> dword index of its entry (one pad entry per 4 columns: conflict-free lane stride).
     // With c = x0 + j and x0 = 4t: index = (5t + d + (d>>2)) * EW, d = j + n >= 0 -- `5t*EW` is the
     // thread's base, the rest folds to an immediate when n is a compile-time constant.
@@ -569,10 +584,79 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         for (int i = 0; i < P; i++) { if (plus) eadd(firE[i], e[i]); else esub(firE[i], e[i]); }
     };
 
-    // FIR rows [0, min(h, n-1)) enter before the loop; row y+n-1 enters at step y
-    for (int yy = 0; yy < min(h, n - 1); yy++) {
-        RowRegs<C, P> r = load_row(yy, xl);
-        fir_apply(r, true);
+    // rows in front of the band: copies of the image
+    auto copy_rows = [&](int ya, int yb) {
+        constexpr int CB = 8;                           // rows per batch; the next batch's loads go out before this one's stores
+        auto ld = [&](int yy, unsigned (&v)[CB][ND]) {
+#pragma unroll
+            for (int k = 0; k < CB; k++) {
+                gc_u32p p = (gc_u32p)((img + (size_t)min(yy + k, yb - 1) * ipitch) + vo_px);
+#pragma unroll
+                for (int q = 0; q < ND; q++) v[k][q] = p[q];
+            }
+        };
+        auto st = [&](int yy, const unsigned (&v)[CB][ND]) {
+            if (!act) return;
+#pragma unroll
+            for (int k = 0; k < CB; k++) {
+                if (yy + k < yb) {             // (no early exit: the loop must unroll, v[k] are registers)
+                    uint8_t *o = out + (size_t)(yy + k) * opitch + (size_t)x0 * C;
+                    if (x0 + P <= XE) {
+#pragma unroll
+                        for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = v[k][q];
+                    } else {
+                        const int nbytes = (XE - x0) * C;
+#pragma unroll
+                        for (int j = 0; j < P * C; j++)
+                            if (j < nbytes) ((g_u8p)(uintptr_t)o)[j] = (uint8_t)(v[k][j >> 2] >> (8 * (j & 3)));
+                    }
+                }
+            }
+        };
+        if (ya >= yb) return;
+        unsigned va[CB][ND], vb[CB][ND];
+        ld(ya, va);
+        for (int yy = ya; yy < yb; yy += 2 * CB) {
+            if (yy + CB < yb) ld(yy + CB, vb);
+            st(yy, va);
+            if (yy + CB < yb) {
+                if (yy + 2 * CB < yb) ld(yy + 2 * CB, va);
+                st(yy + CB, vb);
+            }
+        }
+    };
+    if (band) copy_rows(band->c0, band->y0);
+    if (yb1 > yb0) {
+    // The sums in front of the band's first row yb0: FIR rows [yb0-1-n, yb0+n-1) (row y+n-1 enters, row y-n-1 leaves at
+    // step y), IIR rows [yb0-n, yb0-1) -- image rows, the outputs there are copies -- and `prev` = row yb0-1, which step
+    // yb0 adds.  A band at the top of the page starts from nothing, like the whole page.  Five rows in flight.
+    {
+        const int pa = max(0, yb0 - 1 - n), pb = min(h, yb0 + n - 1);
+        constexpr int WB = 5;
+        for (int yy = pa; yy < pb; yy += WB) {
+            RowRegs<C, P> r[WB];
+#pragma unroll
+            for (int k = 0; k < WB; k++) r[k] = load_row(min(yy + k, pb - 1), xl);
+#pragma unroll
+            for (int k = 0; k < WB; k++) {
+                const int yr = yy + k;
+                if (yr < pb) fir_apply(r[k], true);
+                if (yr < pb && yr >= yb0 - n && yr < yb0) {
+                    unsigned o[ND];
+#pragma unroll
+                    for (int q = 0; q < ND; q++) o[q] = r[k].px[q] & pxm[q];
+                    if (yr < yb0 - 1) {
+                        Ent e[P];
+                        iir_entries(o, e);
+#pragma unroll
+                        for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < ND; q++) prev[q] = o[q];
+                    }
+                }
+            }
+        }
     }
     // The inputs of a row (entering / leaving / current image row, leaving output row, STRIP: the neighbour's granules)
     // are loaded one row ahead.  Two sets of them alternate -- the row loop is unrolled by two, row y consumes one set
@@ -583,9 +667,9 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         u32x4 mbp, mbl;            // STRIP: granules in flight
     };
     RowSet SA, SB;
-    SA.e = load_row(n - 1, xl);
-    SA.l = load_row(0, xl);
-    SA.c = load_row(0, xl);
+    SA.e = load_row(yb0 + n - 1, xl);
+    SA.l = load_row(yb0 - n - 1, xl);
+    SA.c = load_row(yb0, xl);
     SA.mbp = u32x4{0, 0, 0, 0}; SA.mbl = u32x4{0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < ND; q++) SA.ol[q] = 0;
@@ -612,7 +696,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     float kf[P];
     int dxw[P];
 #pragma unroll
-    for (int i = 0; i < P; i++) { kf[i] = 0.0f; dxw[i] = (x0 + i) - max(0, x0 + i - n); }
+    for (int i = 0; i < P; i++) { dxw[i] = (x0 + i) - max(0, x0 + i - n); kf[i] = (float)(min(yb0, n) * dxw[i]); }
     auto do_row = [&](const int y, RowSet &RS, RowSet &NS) {
         // ---- this row's inputs (loaded a row ago) have landed: only now the previous row's store and the next row's
         // loads go out ----
@@ -622,7 +706,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
             for (int q = 0; q < ND; q++) asm volatile("" : "+v"(RS.e.px[q]), "+v"(RS.l.px[q]), "+v"(RS.c.px[q]), "+v"(RS.ol[q]) : : "memory");
         }
-        if (y >= 1) store_row(y - 1, prev);
+        if (y > yb0) store_row(y - 1, prev);         // (row yb0-1 in front of a band is a copy, written with the copies)
         // STRIP: the next row's granules.  The loads are asm statements the compiler takes for finished: they stay in
         // these locals, untouched, until the `s_waitcnt` at the bottom of this row, and only then move into the next
         // row's set (a register copy between an asynchronous load and its wait would read the old contents)
@@ -658,7 +742,10 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         NS.l = load_row(yn - n - 1, xl);
         NS.c = load_row(yn, xl);
         {
-            gc_u32p p = (gc_u32p)((out + (size_t)min(max(yn - n - 1, 0), h - 1) * opitch) + vo_px);
+            // the output row that leaves the IIR sums at the next step; in front of the band it is the image row
+            const int yl = min(max(yn - n - 1, 0), h - 1);
+            const uint8_t *lrow = yl < yb0 ? img + (size_t)yl * ipitch : out + (size_t)yl * opitch;
+            gc_u32p p = (gc_u32p)(lrow + vo_px);
 #pragma unroll
             for (int q = 0; q < ND; q++) NS.ol[q] = p[q];
         }
@@ -672,7 +759,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
 #pragma unroll
             for (int i = 0; i < P; i++) eadd(iirE[i], e[i]);
         }
-        if (y - n - 1 >= 0 && n >= 1) {
+        if (y - n - 1 >= 0 && n >= 1 && y > yb0) {          // (a band's first row: its IIR sums were built without that row)
             unsigned ol[ND];
 #pragma unroll
             for (int q = 0; q < ND; q++) ol[q] = RS.ol[q] & pxm[q];
@@ -854,11 +941,13 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             NS.mbp = nmbp; NS.mbl = nmbl;
         }
     };
-    for (int y = 0; y < h; y += 2) {
+    for (int y = yb0; y < yb1; y += 2) {
         do_row(y, SA, SB);
-        if (y + 1 < h) do_row(y + 1, SB, SA);
+        if (y + 1 < yb1) do_row(y + 1, SB, SA);
     }
-    if (h >= 1) store_row(h - 1, prev);
+    store_row(yb1 - 1, prev);
+    }
+    if (band) copy_rows(band->y1, band->c1);
 }
 
 // Rows of 4097..8160 columns: the same packed scheme with TWO groups of 4 columns per thread (columns
@@ -1152,6 +1241,148 @@ __global__ __launch_bounds__(MAXT) void optimise_strip_kernel(const OptJob *jobs
     }
 }
 
+// Bands of every job of a launch (see OptBand).  One workgroup per job: row flags ("has an unselected pixel") from the
+// 1-bpp mask rows, band starts (a flagged row with no flagged row among the n above it) and ends (none among the n below),
+// one queue entry per band.  Queue layout: slots [0, njobs) hold at most one LONG band per job (more than half the page:
+// the whole page of an fg layer) or an empty entry, so that the walkers start with the long chains; every other band is
+// appended behind them (qctl[0] counts those).
+__global__ __launch_bounds__(1024) void opt_bands_kernel(const OptJob *jobs, OptBand *q, unsigned *qctl, int njobs) {
+    extern __shared__ unsigned bb[];                 // flag bits | start bits | end bits, nw words each
+    const OptJob J = jobs[blockIdx.x];
+    const int h = J.h, w = J.w, n = J.n, nw = (h + 31) >> 5;
+    unsigned *fb = bb, *sb = bb + nw, *eb = bb + 2 * nw;
+    const int t = threadIdx.x, NT = 1024;
+    for (int i = t; i < 3 * nw; i += NT) bb[i] = 0;
+    if (t == 0) q[blockIdx.x] = OptBand{(int)blockIdx.x, 0, 0, 0, 0, {0, 0, 0}};
+    __syncthreads();
+    if (J.rowflags) {
+        // the producer of the bit rows left one byte per row: an fg-like layer (unselected = clear bits) is one band anyway
+        if (!J.invert) {
+            if (t == 0) q[blockIdx.x] = OptBand{(int)blockIdx.x, 0, 0, h, h, {0, 0, 0}};
+            return;
+        }
+        for (int y = t; y < h; y += NT)
+            if (J.rowflags[y]) atomicOr(&fb[y >> 5], 1u << (y & 31));
+    } else {
+        // one wave per row, four rows in flight: lanes OR the row's words (rows of up to 4096 columns: two words per lane)
+        const int wave = t >> 6, lane = t & 63, wpr = (w + 31) >> 5;
+        const unsigned lastm = (w & 31) ? ((1u << (w & 31)) - 1u) : 0xffffffffu;
+        const unsigned inv = J.invert ? 0u : 0xffffffffu;        // unselected = bit clear (or set, for an inverted mask)
+        for (int y0 = 4 * wave; y0 < h; y0 += 4 * (NT / 64)) {
+            unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int y = min(y0 + r, h - 1);
+                for (int k = lane; k < wpr; k += 64) {
+                    unsigned v = J.mbits[(size_t)y * J.mwpr + k] ^ inv;
+                    if (k == wpr - 1) v &= lastm;
+                    acc[r] |= v;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (y0 + r < h && __any(acc[r] != 0u) && lane == 0) atomicOr(&fb[(y0 + r) >> 5], 1u << ((y0 + r) & 31));
+        }
+    }
+    __syncthreads();
+    auto any_in = [&](const unsigned *b, int a, int e) {        // a flagged row in [a, e) (clipped)
+        a = max(a, 0); e = min(e, h);
+        for (int y = a; y < e;) {
+            const int wi = y >> 5, lo = y & 31, cnt = min(32 - lo, e - y);
+            const unsigned m = (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u)) << lo;
+            if (b[wi] & m) return true;
+            y += cnt;
+        }
+        return false;
+    };
+    for (int y = t; y < h; y += NT) {
+        if (!((fb[y >> 5] >> (y & 31)) & 1u)) continue;
+        if (!any_in(fb, y - n, y)) atomicOr(&sb[y >> 5], 1u << (y & 31));
+        if (!any_in(fb, y + 1, y + 1 + n)) atomicOr(&eb[y >> 5], 1u << (y & 31));
+    }
+    __syncthreads();
+    auto next_bit = [&](const unsigned *b, int from) {          // first set bit at or after `from`, h if none
+        for (int wi = from >> 5; wi < nw; wi++) {
+            unsigned v = b[wi];
+            if (wi == (from >> 5)) v &= 0xffffffffu << (from & 31);
+            if (v) return min(h, wi * 32 + __builtin_ctz(v));
+        }
+        return h;
+    };
+    auto prev_bit = [&](const unsigned *b, int before) {        // last set bit before `before`, -1 if none
+        for (int wi = (before - 1) >> 5; wi >= 0 && before > 0; wi--) {
+            unsigned v = b[wi];
+            if (wi == ((before - 1) >> 5) && ((before & 31) != 0)) v &= (1u << (before & 31)) - 1u;
+            if (v) return wi * 32 + 31 - __builtin_clz(v);
+        }
+        return -1;
+    };
+    for (int y = t; y < h; y += NT) {
+        if (!((sb[y >> 5] >> (y & 31)) & 1u)) continue;
+        const int e = next_bit(eb, y);                           // the band's last flagged row (exists: ends and starts alternate)
+        const int pe = prev_bit(eb, y);                          // the band before ends there
+        const int ns = next_bit(sb, e + 1);
+        OptBand b = {(int)blockIdx.x, pe + 1, y, e + 1, ns >= h ? h : e + 1, {0, 0, 0}};
+        if ((b.y1 - b.y0) * 2 > h) q[blockIdx.x] = b;           // at most one such band per job
+        else q[njobs + atomicAdd(&qctl[0], 1u)] = b;
+    }
+    if (t == 0 && next_bit(sb, 0) >= h)                          // no unselected pixel anywhere: the layer is a copy
+        q[njobs + atomicAdd(&qctl[0], 1u)] = OptBand{(int)blockIdx.x, 0, 0, 0, h, {0, 0, 0}};
+}
+
+// a record at a wave-uniform address through the constant address space: scalar loads into scalar registers
+template <class T>
+__device__ __forceinline__ T load_uniform(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    typedef const unsigned __attribute__((address_space(4))) *c_u32p;
+    const c_u32p src = (c_u32p)(uintptr_t)p;
+    T v;
+    unsigned *d = reinterpret_cast<unsigned *>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) d[i] = src[i];
+    return v;
+}
+
+// Walkers: one workgroup per CU takes entries off the queue until it is empty.
+template <int C, int NH, int MAXT, bool DB>
+__global__ __launch_bounds__(MAXT) void optimise_band_kernel(const OptJob *jobs, const OptBand *q, unsigned *qctl, int njobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_idx;
+    const int total = njobs + (int)__builtin_amdgcn_readfirstlane((int)qctl[0]);
+    int zeroed_for_n = -1;                 // the LDS rows' pad entries are zero for this n (the layout depends on it)
+    // Walker b starts with queue entry b -- consecutive workgroups sit on different XCDs, so the long chains at the front of
+    // the queue (the fg pages) spread evenly over the eight L2s, as a launch of one workgroup per page would -- and takes
+    // further entries off the shared counter.
+    for (bool first = true;; first = false) {
+        __syncthreads();                       // everyone has read s_idx of the previous round
+        if (threadIdx.x == 0) s_idx = first ? (int)blockIdx.x : (int)(gridDim.x + atomicAdd(&qctl[1], 1u));
+        __syncthreads();
+        // wave-uniform by construction: make it so for the compiler too (scalar registers for the band, the job record and
+        // every loop bound and row address derived from them; as lane values the row loop's control flow would be divergent)
+        const int idx = __builtin_amdgcn_readfirstlane(s_idx);
+        if (idx >= total) break;
+        const OptBand B = load_uniform(q + idx);
+        if (B.c1 <= B.c0) continue;            // an empty front slot
+        const OptJob J = load_uniform(jobs + B.job);
+        const bool zero = J.n != zeroed_for_n;
+        zeroed_for_n = J.n;
+        // A band that is (nearly) the whole page -- every fg layer -- takes the whole-page instance of the row loop: the
+        // rows outside the band are copies either way, and without the band's bounds that loop is ~30 % leaner in
+        // scalar instructions (measured: fg layers 5.2 -> 4.9 ms per 128 pages).
+        const StripInfo NOSTRIP = StripInfo{1, 0, nullptr, 0, nullptr};
+        const OptBand *bp = (B.y1 - B.y0) * 10 >= J.h * 9 ? nullptr : &B;
+        if (bp) {
+            if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
+            else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
+            else optimise_packed_rows<C, NH, -1, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
+        } else {
+            if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem, NOSTRIP, 0, 0, nullptr, zero);
+            else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, nullptr, zero);
+            else optimise_packed_rows<C, NH, -1, DB, true>(J, smem, NOSTRIP, 0, 0, nullptr, zero);
+        }
+    }
+}
+
 // Self-test of the quotient both optimise kernels use: (unsigned)fma((float)v, rcp(cnt), rcp(cnt)/2) against
 // v / cnt for EVERY count the kernels can produce (1 .. 5120 = (2n)^2 + n^2 at n = 32) and every value
 // 0 .. 255*cnt (a window of cnt bytes): ~3.3e9 pairs.
@@ -1283,9 +1514,13 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     }
     int n_min = n_max;
     for (int i = 0; i < njobs; i++) n_min = std::min(n_min, h_jobs[i].n);
-    const double alg_all = (1.0 + 2.0 * c) * w * h * njobs;
-    if (ws_supported(w, h, n_max, n_min)) {
-        // the wave-strip schedule reads the mask at 1 bit per pixel: callers that only have bytes get a packed copy
+    OptGeom g;
+    TRY(opt_geometry(w, c, n_max, &g));
+    // Whole rows of <= 4096 columns on one workgroup, n <= 11: the band walkers (optimise_band_kernel).  They read the
+    // mask at 1 bit per pixel: callers that only have bytes get a packed copy.
+    static const bool no_bands = getenv("MRCHIP_OPT_BANDS") && atoi(getenv("MRCHIP_OPT_BANDS")) == 0;
+    const bool bands = !no_bands && g.P == 4 && n_max <= 11 && n_min >= 1 && h < 65536;
+    if (bands) {
         const int wpr = cdiv(w, 32);
         const size_t per = (size_t)wpr * h * sizeof(unsigned);
         size_t missing = 0;
@@ -1311,15 +1546,12 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
                 j.mbits = dst; j.mwpr = wpr;
             }
         }
-        return launch_optimise_ws(ctx, s, h_jobs, d_jobs, njobs, w, h, c, mail, alg_all);
     }
     HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
     {
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
         if (st != 0) return st < 0 ? st : 0;
     }
-    OptGeom g;
-    TRY(opt_geometry(w, c, n_max, &g));
     const double alg = (1.0 + 2.0 * c) * w * h * njobs;
 #define OPT_LAUNCH(CC, PP, MT, NAME)                                                                     \
     do {                                                                                                \
@@ -1358,7 +1590,43 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     const size_t wlds = (size_t)(wnent + wnent / 4 + 1) * ((c == 3) ? 16 : 8);
     static const bool no_wide = getenv("MRCHIP_OPT_NO_WIDE") != nullptr;
     const bool wide_ok = !no_wide && wlds <= 160 * 1024;
-    if (g.P == 4 && n_max <= 11) {
+    if (bands) {
+        // queue: njobs front slots + one entry per band (a band and its gap take more than n_min rows) + control words
+        const size_t cap = (size_t)njobs * (2 + h / (n_min + 1));
+        const size_t need = 256 + cap * sizeof(OptBand);
+        if (mail->bandq_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(s));
+            TRY(mail->bandq.alloc(ctx, need));
+            mail->bandq_bytes = need;
+        }
+        unsigned *qctl = mail->bandq.as<unsigned>();
+        OptBand *q = reinterpret_cast<OptBand *>(mail->bandq.as<unsigned char>() + 256);
+        HIP_TRY(hipMemsetAsync(qctl, 0, 8, s));
+        LAUNCH(ctx, s, "optimise_bands", 0.0,
+               hipLaunchKernelGGL(opt_bands_kernel, dim3(njobs), dim3(1024), 3 * cdiv(h, 32) * sizeof(unsigned), s, d_jobs, q, qctl, njobs));
+        const int cus = ctx->cus > 0 ? ctx->cus : 256;
+        // one walker per CU when the rows need more than half a CU's threads or LDS, else two
+        const int per_cu = (g.T <= 512 && 2 * plds <= 160 * 1024) ? 2 : 1;
+        const int walkers = std::min<long long>((long long)cap, (long long)cus * per_cu);
+#define OPT_BAND2(CC, NHH, MT, DBB, NAME)                                                                \
+    do {                                                                                                \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_band_kernel<CC, NHH, MT, DBB>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));            \
+        LAUNCH(ctx, s, NAME, alg,                                                                       \
+               hipLaunchKernelGGL((optimise_band_kernel<CC, NHH, MT, DBB>), dim3(walkers), dim3(g.T), plds, s, d_jobs, q, qctl, njobs)); \
+    } while (0)
+#define OPT_BAND(CC, NHH, MT, NAME)                                                                      \
+    do { if (db) OPT_BAND2(CC, NHH, MT, true, NAME); else OPT_BAND2(CC, NHH, MT, false, NAME); } while (0)
+        if (c == 3) {
+            if (n_max <= 8) { if (g.T <= 512) OPT_BAND(3, 1, 512, "optimise_rgb"); else OPT_BAND(3, 1, 1024, "optimise_rgb"); }
+            else { if (g.T <= 512) OPT_BAND(3, 2, 512, "optimise_rgb"); else OPT_BAND(3, 2, 1024, "optimise_rgb"); }
+        } else {
+            if (n_max <= 8) { if (g.T <= 512) OPT_BAND(1, 1, 512, "optimise_gray"); else OPT_BAND(1, 1, 1024, "optimise_gray"); }
+            else { if (g.T <= 512) OPT_BAND(1, 2, 512, "optimise_gray"); else OPT_BAND(1, 2, 1024, "optimise_gray"); }
+        }
+#undef OPT_BAND
+#undef OPT_BAND2
+    } else if (g.P == 4 && n_max <= 11) {
         // 16-bit lane capacity: one FIR accumulator up to n=8, two halves up to n=11
         if (c == 3) {
             if (n_max <= 8) { if (g.T <= 512) OPT_PACKED(3, 1, 512, "optimise_rgb"); else OPT_PACKED(3, 1, 1024, "optimise_rgb"); }

@@ -217,10 +217,9 @@ struct OptJob {
     // optional: the same mask at 1 bit per pixel (LSB first, mwpr dwords per row) as the denoiser leaves it;
     // the packed kernel reads it instead of the byte mask (an eighth of the traffic of 3 reads per row)
     const unsigned *mbits; int mwpr;
-    // wave-strip schedule (k_optimise_ws.hip), filled by the launcher: strips of this job, core lanes per strip, first
-    // granule of the job's part of the hand-off buffer
-    int ws_S, ws_clb;
-    size_t ws_mail;
+    // optional, with mbits: one byte per row, 1 = the row of the (uninverted) bit mask has a set pixel (the denoiser leaves
+    // them); saves the band scan its pass over the bit rows
+    const uint8_t *rowflags;
 };
 // hand-off buffer of the strip schedules (one per owner that may have a launch in flight: a batch, or a host-buffer
 // call).  The first 256 bytes of `buf` are unused padding; `err` is a page-locked host word the kernels set when a
@@ -232,6 +231,8 @@ struct OptMail {
     unsigned *err = nullptr;
     DevBuf bits;              // 1-bpp copy of a byte mask for callers that have none (host-buffer entry point)
     size_t bits_bytes = 0;
+    DevBuf bandq;             // queue of the band walkers: 256 bytes of control words + OptBand entries
+    size_t bandq_bytes = 0;
     OptMail() = default;
     OptMail(const OptMail &) = delete;
     OptMail &operator=(const OptMail &) = delete;
@@ -244,9 +245,6 @@ int optmail_check(OptMail *mail);
 // it must stay valid until the copy has run)
 int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
                          int n_max, OptMail *mail);
-bool ws_supported(int w, int h, int n_max, int n_min);
-int launch_optimise_ws(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
-                       OptMail *mail, double alg);
 // bytes != 0 -> 1 bit per pixel, LSB first, wpr dwords per row (the denoiser's rows)
 int launch_pack_bits(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int pitch, int w, int h, unsigned *bits, int wpr);
 
@@ -322,9 +320,12 @@ void gauss_pad_weights(GaussW &g, int R);
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
                           float *tmp, int tpitch, size_t tstride, int npages, int max_radius);
 // bits: page i at bits + i*bits_stride dwords
+// want_rowflags: also leave one byte per row ("the finished row has a set pixel") at denoise_rowflags_offset(w, h) of
+// each page's scratch (n = 2, mincnt = 4 path only)
 int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int h, int mincnt, int n, unsigned *bits,
-                         size_t bits_stride, int npages, bool bits_ready = false);
+                         size_t bits_stride, int npages, bool bits_ready = false, bool want_rowflags = false);
 size_t denoise_scratch_bytes(int w, int h);
+size_t denoise_rowflags_offset(int w, int h);
 int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_bad);
 // d_bad_tested[0] += mismatching, [1] += tested (mean, px, var) triples of the decision table of (k, R)
 int sauvola_table_selftest(mrchip_ctx *ctx, hipStream_t s, double k, double R, unsigned long long *d_bad_tested, int *table_bytes);

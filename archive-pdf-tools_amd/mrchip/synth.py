@@ -199,3 +199,10 @@ def synth_pages(specs, threads=None):
         return [synth_page(**sp) for sp in specs]
     with ThreadPoolExecutor(threads) as ex:
         return list(ex.map(lambda sp: synth_page(**sp), specs))
+
+
+def two_level_page(w, h):
+    """RGB page of 0 / 255 blocks (9 x 7 px checker): the largest variances a window can have."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.where((yy // 9 + xx // 7) % 2 == 0, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(a[:, :, None], 3, axis=2))

@@ -160,9 +160,9 @@ def git_head():
 
 
 # kernel symbol (as rocprofv3 prints it) behind a profile name; the page and the hOCR-box launches of Sauvola are two
-# instances of one template (the 4th argument: both polarities)
-KERNEL_SYMBOL = {'optimise_rgb': r'optimise_packed_kernel<3', 'optimise_gray': r'optimise_packed_kernel<1',
-                 'sauvola': r'sauvola_kernel<\d+, \w+, \w+, false', 'sauvola_boxes': r'sauvola_kernel<\d+, \w+, \w+, true'}
+# instances of one template (the 3rd argument: both polarities)
+KERNEL_SYMBOL = {'optimise_rgb': r'optimise_(band|packed)_kernel<3', 'optimise_gray': r'optimise_(band|packed)_kernel<1',
+                 'sauvola': r'sauvola(_tab)?_kernel<\d+, \w+, false', 'sauvola_boxes': r'sauvola(_tab)?_kernel<\d+, \w+, true'}
 
 
 def _profile_kernel(kernels, name):
@@ -172,14 +172,36 @@ def _profile_kernel(kernels, name):
     return max(hits, key=lambda kv: kv[1].get('launches', 0))[1] if hits else None
 
 
-def pmc_traffic(name, alg_per_launch):
+def _pick_profile(kind, config, inflight):
+    """The newest committed profiles/<round>_*<kind>_summary.json whose bench command ran THIS configuration (--config)
+    with this many batches in flight; None when there is none -- numbers of another workload are not attached."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_summary.json' % kind))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        args = (d.get('bench_args') or '').split()
+
+        def opt(name, default):
+            return args[args.index(name) + 1] if name in args and args.index(name) + 1 < len(args) else default
+        cfgname = opt('--config', 'c2')
+        infl = int(opt('--inflight', CONFIGS.get(cfgname, {}).get('inflight', 1)))
+        if cfgname == config and infl == inflight:
+            best = (f, d)              # sorted: later rounds win
+    return best
+
+
+def pmc_traffic(name, alg_per_launch, config='c2', inflight=3):
     """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
     2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size -- with the provenance, so a
     stale profile cannot pass for a measurement of this build."""
     try:
-        import glob
-        f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))[-1]
-        d = json.load(open(f))
+        hit = _pick_profile('pmc', config, inflight)
+        if not hit:
+            return None, None
+        f, d = hit
         src = {'file': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
         v = _profile_kernel(d['kernels'], name)
         if v and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
@@ -189,26 +211,26 @@ def pmc_traffic(name, alg_per_launch):
         return None, None
 
 
-def valu_roofline(name, alg_per_launch, bytes_per_px):
+def valu_roofline(name, alg_per_launch, bytes_per_px, config='c2', inflight=3):
     """The instruction side of the roofline for kernel `name` from the committed SQ / GRBM counter passes
     (profiles/*_valu_summary.json, written by tools/profile_round.sh beside the FETCH / WRITE passes): VALU
     wave-instructions per 64 pixels (= lane-instructions per pixel), cycles per instruction, VALU-busy fraction."""
     try:
-        import glob
-        f = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_valu_summary.json')))[-1]
-        d = json.load(open(f))
+        hit = _pick_profile('valu', config, inflight)
+        if not hit:
+            return None
+        f, d = hit
         sc = d.get('scale', {}).get(name, {})
         v = _profile_kernel(d['kernels'], name)
-        if True:
-            if v and 'alg_bytes_per_launch' in sc:
-                px = sc['alg_bytes_per_launch'] / bytes_per_px
-                return {'insts_per_px': round(v['valu_wave_insts_per_launch'] / (px / 64.0), 2), 'busy_frac': v['busy_frac'],
-                        'cycles_per_inst': v['cycles_per_inst'],
-                        'what': 'VALU wave-instructions per 64 pixels; fraction of the launch a SIMD VALU was busy; issue '
-                                'cycles per instruction -- at ~4 cycles each and 1024 SIMDs x 2.4 GHz the chip issues 39 T '
-                                'lane-instructions/s, i.e. 0.6 of the byte roofline needs <= 16 per Sauvola pixel, <= 57 per '
-                                'optimise RGB pixel',
-                        'source': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
+        if v and 'alg_bytes_per_launch' in sc:
+            px = sc['alg_bytes_per_launch'] / bytes_per_px
+            return {'insts_per_px': round(v['valu_wave_insts_per_launch'] / (px / 64.0), 2), 'busy_frac': v['busy_frac'],
+                    'cycles_per_inst': v['cycles_per_inst'],
+                    'what': 'VALU wave-instructions per 64 pixels; fraction of the launch a SIMD VALU was busy; issue '
+                            'cycles per instruction -- at ~4 cycles each and 1024 SIMDs x 2.4 GHz the chip issues 39 T '
+                            'lane-instructions/s, i.e. 0.6 of the byte roofline needs <= 16 per Sauvola pixel, <= 57 per '
+                            'optimise RGB pixel',
+                    'source': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
         return None
     except Exception:
         return None
@@ -234,11 +256,32 @@ def spawn_ranks(n, argv):
     def drain(r):                       # all pipes are read at once: no rank ever blocks on a full one
         outs[r] = procs[r].communicate()[0]
 
-    ths = [threading.Thread(target=drain, args=(r,)) for r in range(n)]
+    ths = [threading.Thread(target=drain, args=(r,), daemon=True) for r in range(n)]
     for th in ths:
         th.start()
+    # A rank that dies early (GPU fault, import error) leaves the others inside a collective: watch the children, and
+    # once one has failed give the rest a grace period, then end them (fresh children of this process, by PID); the whole
+    # run is bounded as well.
+    deadline = time.time() + float(os.environ.get('MRCHIP_BENCH_TIMEOUT', '3600'))
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = now
+        if (failed_at is not None and now - failed_at > 20.0) or now > deadline:
+            why = 'a rank failed' if failed_at is not None else 'timeout'
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    sys.stderr.write('bench.py: ending rank %d (pid %d): %s\n' % (r, p.pid, why))
+                    p.terminate()
+            time.sleep(3.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     for th in ths:
-        th.join()
+        th.join(30.0)
     lines = [ln for ln in outs[0].splitlines() if ln.startswith('{')]
     for r, out in enumerate(outs):
         for ln in out.splitlines():
@@ -499,12 +542,12 @@ def main():
         ms = r['ms'] / r['launches']
         alg = r['alg_bytes'] / r['launches']
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, src = pmc_traffic(name, alg)
+        traffic, src = pmc_traffic(name, alg, a.config, nb)
         bpp = {'optimise_rgb': 7.0, 'optimise_gray': 3.0, 'sauvola': 2.0, 'sauvola_boxes': 4.0}.get(name)
         return {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': src,
                 'avg_launch_ms': round(ms, 4), 'launches': r['launches'], 'alg_bytes_per_launch': alg,
-                'valu': valu_roofline(name, alg, bpp) if bpp else None}
+                'valu': valu_roofline(name, alg, bpp, a.config, nb) if bpp else None}
 
     # The dominant kernel: the one with the largest share of GPU time when kernels have the chip to themselves (the
     # isolated pass, when it ran).  With several batches in flight a launch's HIP-event duration includes the time it
@@ -529,6 +572,14 @@ def main():
         if sauvola_roof and 'sauvola' in prof_iso:
             si = roofline_of('sauvola', prof_iso)
             sauvola_roof['isolated'] = {'achieved': si['achieved'], 'frac': si['frac'], 'avg_launch_ms': si['avg_launch_ms']}
+    copy_gbps = extra.get('hbm_copy_GBps_measured')
+    if copy_gbps:
+        # against what a plain device copy of the same bytes reaches on THIS box (the spec peak is not reachable by any kernel)
+        for rf in (roof, sauvola_roof):
+            if rf:
+                rf['frac_of_measured_copy'] = round(rf['achieved'] / copy_gbps, 4)
+                if 'isolated' in rf:
+                    rf['isolated']['frac_of_measured_copy'] = round(rf['isolated']['achieved'] / copy_gbps, 4)
     kernels = {k: {'ms_per_launch': round(v['ms'] / v['launches'], 4), 'launches': v['launches'],
                    'alg_GBps': round(v['alg_bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in sorted(prof.items())}
     alg_per_step = sum(v['alg_bytes'] for v in prof.values()) / max(a.steps, 1)
@@ -549,6 +600,7 @@ def main():
                                    'and the time only)', 'control_plane': transport},
             'roofline': roof, 'cpu_baseline': cpu,
             'pipeline_alg_GBps': round(alg_per_step / step_s / 1e9, 1),      # all kernels' algorithmic bytes / step time
+            'pipeline_frac': round(alg_per_step / step_s / 1e9 / (HBM_PEAK_GBS * world), 4),      # ... of the HBM peak of the GPUs used
             'pages_per_s': round(total_pages / dt, 2),
             'sauvola_roofline': sauvola_roof,      # BASELINE.json also names "Sauvola HBM GB/s"
             'kernels': kernels, 'device': info['name'].strip(), 'head': git_head(),
@@ -757,8 +809,14 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
                             st['lock'].wait(0.05)
                     ctypes.memmove(ring[i % RING].ctypes.data, arrs[i].ctypes.data, arrs[i].nbytes)   # a foreign call: no GIL
                     ready[i].set()
+            go = threading.Event()          # set by the timed loop right after its clock starts: nothing is copied off the clock
+            state['go'] = go
+
+            def gated(k):
+                go.wait()
+                producer(k)
             for k in range(RING_THREADS):
-                threading.Thread(target=producer, args=(k,), daemon=True).start()
+                threading.Thread(target=gated, args=(k,), daemon=True).start()
 
             def pages():
                 for i in range(n_fresh):
@@ -771,7 +829,8 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
             with st['lock']:
                 st['taken'] = n
                 st['lock'].notify_all()
-        res['pinned_ring'], out_bytes = run_stream_ring(mrc, ctx, comm, cfg, pool, ring_factory, took, world, W * H * Cc)
+        res['pinned_ring'], out_bytes = run_stream_ring(mrc, ctx, comm, cfg, pool, ring_factory, took, world, W * H * Cc,
+                                                        lambda: state['go'].set())
         res['pinned_ring']['source'] = ('%d distinct pageable arrays copied by a producer thread into a ring of %d page-locked '
                                         'buffers ahead of the stream (%d copy threads)' % (n_fresh, RING, RING_THREADS))
         keep.clear()
@@ -798,17 +857,19 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     return out
 
 
-def run_stream_ring(mrc, ctx, comm, cfg, pool, factory, took, world, in_bytes):
+def run_stream_ring(mrc, ctx, comm, cfg, pool, factory, took, world, in_bytes, start_producers):
     """the pinned-ring variant of e2e_stream's timed loop: both passes report the pages handed out to the producer"""
     out_bytes = 0
     res = None
     for timed in (False, True):
         phases = {}
-        gen = mrc.decompose_stream(factory(), dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
+        pages = factory()                # allocates this pass's fresh arrays and parks the producer threads
+        gen = mrc.decompose_stream(pages, dpi=cfg['dpi'], bg_downsample=cfg['bg'], fg_downsample=cfg['fg'],
                                    batch_pages=E2E_BATCH, slots=E2E_SLOTS, mask_format='packed', pool=pool, stats=phases)
         if timed:
-            comm.barrier()
+            comm.barrier()               # every rank has its arrays
         t0 = time.perf_counter()
+        start_producers()
         n = 0
         for m, fg, bg in gen:
             n += 1
@@ -820,7 +881,7 @@ def run_stream_ring(mrc, ctx, comm, cfg, pool, factory, took, world, in_bytes):
             dt = comm.max_f64(time.perf_counter() - t0)
             res = {'pages_per_s': round(n * world / dt, 1), 'h2d_GBps_per_gpu': round(n * in_bytes / dt / 1e9, 1),
                    'd2h_GBps_per_gpu': round(n * out_bytes / dt / 1e9, 1), 'seconds': round(dt, 3),
-                   'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}}
+                   'host_phase_seconds': {k: round(v, 3) for k, v in phases.items()}, 'pages_copied_before_the_clock': 0}
     return res, out_bytes
 
 

@@ -20,6 +20,9 @@ Files written next to this script:
                   config 4 cycles through them), config-3 pages (3300x4600 gray thresholds and RGB full)
   modes.npz       small pages in PIL modes other than L / RGB (convert('L') of the original, mrc.py:359-361)
                   and create_threshold_mask vectors
+  scans.npz       scan-like and adversarial pages, inputs included: JPEG-decoded text in a real (bitmap) font, a photo
+                  region, a black scanner border, a white-on-black block, ink in every row, line pitch below the bg radius,
+                  constant and two-level pages (+ the last three at config-2 size as digests)
 """
 import hashlib
 import json
@@ -357,8 +360,137 @@ def modes():
     np.savez_compressed(os.path.join(HERE, 'modes.npz'), **d)
 
 
+# ---- scan-like and adversarial pages ------------------------------------------------------------
+# The inputs are stored in the fixture (a JPEG round trip is not reproducible across libjpeg builds), the outputs are
+# the real reference's.  Text is PIL's bundled bitmap font scaled up; recode.py:343-348 feeds decoded JPEG / JP2 scans.
+_WORDS = ('the quick brown fox jumps over a lazy dog while internet archive scans books page by page and '
+          'mixed raster content keeps text sharp in small files').split()
+
+
+def _text_page(w, h, seed, scale=2, pitch=None, color=(30, 28, 35), paper=(226, 220, 204), margin=24):
+    from PIL import ImageDraw, ImageFont
+    rng = np.random.RandomState(seed)
+    font = ImageFont.load_default()
+    lw, lh = (w - 2 * margin) // scale, 11
+    pitch = pitch or (lh * scale + 6)
+    img = np.empty((h, w, 3), np.uint8)
+    img[:] = paper
+    lines = []
+    y = margin
+    while y + lh * scale < h - margin:
+        words = [_WORDS[rng.randint(len(_WORDS))] for _ in range(40)]
+        text, used = '', []
+        for wd in words:
+            if (len(text) + len(wd) + 1) * 6 > lw:
+                break
+            text += (' ' if text else '') + wd
+            used.append(wd)
+        strip = Image.new('L', (lw, lh), 0)
+        ImageDraw.Draw(strip).text((0, 0), text, fill=255, font=font)
+        a = np.array(strip.resize((lw * scale, lh * scale), Image.BICUBIC), dtype=np.float32) / 255.0
+        a = np.clip(a, 0, 1)[..., None]
+        x0 = margin
+        reg = img[y:y + lh * scale, x0:x0 + lw * scale].astype(np.float32)
+        img[y:y + lh * scale, x0:x0 + lw * scale] = (reg * (1 - a) + np.array(color, np.float32) * a + 0.5).astype(np.uint8)
+        ink_w = min(lw * scale, len(text) * 6 * scale)
+        lines.append({'bbox': [x0 - 3, y - 3, x0 + ink_w + 3, y + lh * scale + 3],
+                      'words': [{'text': wd, 'confidence': 91} for wd in used]})
+        y += pitch
+    hocr = [{'lines': lines[i:i + 5]} for i in range(0, len(lines), 5)]
+    return img, hocr
+
+
+def _jpeg(img, quality=75):
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, 'JPEG', quality=quality)
+    return np.array(Image.open(io.BytesIO(buf.getvalue())).convert('RGB' if img.ndim == 3 else 'L'))
+
+
+def scan_cases():
+    W, H = 440, 600
+    rng = np.random.RandomState(4242)
+    out = []
+    img, hocr = _text_page(W, H, 1)
+    out.append(('jpeg_text', _jpeg(img), hocr, {}))
+    # a photo-like smooth region in the middle of the text
+    img, hocr = _text_page(W, H, 2)
+    yy, xx = np.mgrid[0:200, 0:300].astype(np.float32)
+    photo = np.stack([128 + 90 * np.sin(xx / 37.0 + yy / 53.0), 120 + 80 * np.cos(xx / 29.0 - yy / 41.0),
+                      110 + 70 * np.sin((xx + yy) / 61.0)], axis=-1)
+    photo += 40 * np.exp(-((xx - 150) ** 2 + (yy - 90) ** 2) / 3000.0)[..., None]
+    img[200:400, 70:370] = np.clip(photo, 0, 255).astype(np.uint8)
+    out.append(('jpeg_photo', _jpeg(img, 80), hocr, {}))
+    # black scanner border, 40 px, slightly noisy
+    img, hocr = _text_page(W, H, 3, margin=60)
+    b = np.zeros_like(img)
+    b[:] = 6
+    b[40:-40, 40:-40] = img[40:-40, 40:-40]
+    b = np.clip(b.astype(np.int32) + rng.randint(-5, 6, b.shape), 0, 255).astype(np.uint8)
+    out.append(('scanner_border', _jpeg(b), hocr, {}))
+    # a white-on-black block under hOCR boxes
+    img, hocr = _text_page(W, H, 4)
+    blk, bh = _text_page(W, 180, 5, color=(240, 240, 235), paper=(18, 16, 20))
+    img[240:420] = blk
+    for par in bh:
+        for ln in par['lines']:
+            ln['bbox'][1] += 240; ln['bbox'][3] += 240
+    hocr = [p for p in hocr if all(ln['bbox'][3] < 236 or ln['bbox'][1] > 424 for ln in p['lines'])] + bh
+    out.append(('white_on_black', _jpeg(img), hocr, {}))
+    # ink in every row: a vertical rule down the page plus dense text
+    img, hocr = _text_page(W, H, 6, pitch=24)
+    img[:, 12:15] = (25, 25, 30)
+    img[:, W - 9:W - 7] = (40, 30, 30)
+    out.append(('ink_every_row', _jpeg(img), hocr, {}))
+    # line pitch below the bg radius: 11-px glyphs every 14 rows (gaps of 3 rows)
+    img, hocr = _text_page(W, H, 7, scale=1, pitch=14)
+    out.append(('tight_pitch', _jpeg(img, 85), hocr, {}))
+    # gray scan
+    img, hocr = _text_page(W, H, 8)
+    g = np.array(Image.fromarray(img).convert('L'))
+    out.append(('jpeg_gray', _jpeg(g), hocr, {}))
+    # extreme pages: constant and two-level
+    for name, arr in (('all0', np.zeros((300, 400, 3), np.uint8)), ('all255', np.full((300, 400, 3), 255, np.uint8)),
+                      ('two_level', np.where(((np.mgrid[0:300, 0:400][0] // 9 + np.mgrid[0:300, 0:400][1] // 7) % 2 == 0)[..., None],
+                                             np.uint8(0), np.uint8(255)).repeat(3, axis=2).astype(np.uint8))):
+        out.append((name, arr, [{'lines': [{'bbox': [20, 30, 380, 80], 'words': [{'text': 'x', 'confidence': 95}]}]}], {}))
+    return out
+
+
+def scans():
+    d = {}
+    meta = []
+    for i, (name, img, hocr, kw) in enumerate(scan_cases()):
+        td, er = [], set()
+        g = mrc.create_mrc_hocr_components(Image.fromarray(img), hocr, dpi=kw.get('dpi'), bg_downsample=3,
+                                           denoise_mask='fast', timing_data=td, errors=er)
+        m = next(g).copy(); fg = next(g); bg = next(g)
+        d['sc_img_%d' % i] = img
+        d['sc_mask_%d' % i] = np.packbits(m, axis=1)
+        d['sc_fg_%d' % i] = fg
+        d['sc_bg_%d' % i] = bg
+        rows = m.any(axis=1)
+        meta.append({'name': name, 'hocr': hocr, 'keys': [k for k, _ in td], 'errors': sorted(er), 'mask_sum': int(m.sum()),
+                     'ink_rows': int(rows.sum()), 'h': int(img.shape[0])})
+        print('  %-16s mask %7d px, %4d of %d rows with ink' % (name, m.sum(), rows.sum(), img.shape[0]))
+    d['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'scans.npz'), **d)
+    # the same extremes at config-2 size: digests only (the GPU box regenerates the inputs)
+    dj = json.load(open(os.path.join(HERE, 'digests.json')))
+    for name, arr in (('c2_all0', np.zeros((3000, 4000, 3), np.uint8)), ('c2_all255', np.full((3000, 4000, 3), 255, np.uint8)),
+                      ('c2_two_level', synth.two_level_page(4000, 3000))):
+        hocr = [{'lines': [{'bbox': [200, 300, 3800, 420], 'words': [{'text': 'x', 'confidence': 95}]}]}]
+        t0 = time.time()
+        g = mrc.create_mrc_hocr_components(Image.fromarray(arr), hocr, dpi=None, bg_downsample=3, denoise_mask='fast')
+        m = next(g).copy(); fg = next(g); bg = next(g)
+        dj[name] = {'in': sha(arr), 'mask': sha(m), 'fg': sha(fg), 'bg': sha(bg), 'bg_shape': list(bg.shape), 'mask_sum': int(m.sum()),
+                    'ref_seconds': round(time.time() - t0, 2)}
+        print('  %s done' % name)
+    json.dump(dj, open(os.path.join(HERE, 'digests.json'), 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests', 'c5_extra', 'configs', 'modes']
+    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests', 'c5_extra', 'configs', 'modes', 'scans']
     for name in which:
         t0 = time.time()
         globals()[name]()

@@ -87,3 +87,26 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr
+
+
+def test_eight_ranks_dry_run():
+    """Dress rehearsal of the N = 8 launcher path without a GPU: eight children, one line, page i -> rank i mod 8."""
+    r = _run_bench(['--gpus', '8'], {'MRCHIP_BENCH_DRYRUN': '1'}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and [x['rank'] for x in d['ranks']] == list(range(8))
+    assert [x['pages'] for x in d['ranks']] == [[i] for i in range(8)]
+
+
+def test_profile_figures_are_only_attached_to_the_configuration_they_were_taken_on():
+    """the newest *_summary.json used to be quoted for every --config / --inflight."""
+    import bench
+    hit = bench._pick_profile('pmc', 'c3gray', bench.CONFIGS['c3gray']['inflight'])
+    assert hit and 'c3gray' in os.path.basename(hit[0])
+    hit = bench._pick_profile('valu', 'c2', 1)
+    assert hit and 'inflight1' in os.path.basename(hit[0])
+    assert bench._pick_profile('pmc', 'c5', bench.CONFIGS['c5']['inflight']) is None
+    assert bench.pmc_traffic('optimise_rgb', 1e9, 'c5', bench.CONFIGS['c5']['inflight']) == (None, None)
+    assert bench.valu_roofline('sauvola', 1e9, 2.0, 'c5', 3) is None

@@ -258,38 +258,72 @@ def test_optimise_whole_rows_and_column_strips_agree_with_the_oracle(monkeypatch
             assert np.array_equal(got, exp), ((h, w, c, n, dens), mode, int((got != exp).sum()))
 
 
-WS_CHECK = r'''
-import os, sys
-import numpy as np
-sys.path.insert(0, os.path.join(%(root)r, 'archive-pdf-tools_amd')); sys.path.insert(0, os.path.join(%(root)r, 'oracle'))
-import mrc_oracle as O
-from mrchip import _lib, synth
-lib = _lib.load(); ctx = _lib.default_context()
-bad = []
-for (w, h, c, seed, ns) in [(450, 350, 3, 4, 12.0), (1000, 600, 3, 9, 6.0), (230, 300, 1, 1, 6.0), (777, 401, 1, 3, 2.0), (2500, 700, 3, 5, 6.0)]:
-    img, hocr = synth.synth_page(w, h, c, seed=seed, noise_sigma=ns, line_div=16)
-    mask = next(O.create_mrc_hocr_components(img, hocr, denoise_mask='fast')).astype(np.uint8)
-    for n, inv in ((3, 0), (10, 1), (5, 0), (7, 1), (2, 1)):
-        mi = (1 - mask) if inv else mask
-        exp = (O.optimise_rgb2 if c == 3 else O.optimise_gray2)(mi, img, w, h, n)
-        for rep in range(2):
-            got = np.empty_like(img)
-            _lib.check(lib.mrchip_optimise(ctx.handle, _lib.ptr(mask), _lib.ptr(img), _lib.ptr(got), w, h, c, n, inv))
-            if not np.array_equal(exp, got):
-                bad.append((w, h, c, n, inv, int((exp != got).sum())))
-print('WS_BAD', bad)
-'''
+def _band_masks(rng, h, w, n):
+    """Masks (1 = selected = copied) whose unselected rows come in runs separated by gaps of chosen lengths."""
+    out = []
+    def rows_to_mask(rows, dens=0.3):
+        m = np.ones((h, w), np.uint8)
+        for y in rows:
+            if 0 <= y < h:
+                m[y] = (rng.rand(w) >= dens).astype(np.uint8)
+        return m
+    for gap in (n - 1, n, n + 1, 2 * n + 3):               # rows 20.., then a gap of `gap` selected rows, then more
+        rows = list(range(20, 26)) + list(range(26 + gap, 26 + gap + 5))
+        out.append(('gap%d' % gap, rows_to_mask(rows)))
+    out.append(('row0', rows_to_mask([0, 1, 2 + n + 5, h - 1])))
+    out.append(('lastrow', rows_to_mask([h - 1])))
+    out.append(('firstrow_only', rows_to_mask([0])))
+    out.append(('single_pixel', rows_to_mask([])))
+    out[-1][1][h // 2, w // 3] = 0
+    out.append(('no_gaps', rows_to_mask(range(h), dens=0.02)))
+    out.append(('all_selected', np.ones((h, w), np.uint8)))
+    out.append(('none_selected', np.zeros((h, w), np.uint8)))
+    out.append(('every_nth', rows_to_mask(range(3, h, n + 1))))          # gaps of exactly n rows all the way down
+    out.append(('every_n', rows_to_mask(range(3, h, n))))                # gaps of n - 1: one band
+    out.append(('random_rows', rows_to_mask([y for y in range(h) if rng.rand() < 0.06])))
+    left = np.ones((h, w), np.uint8); left[40:45, :3] = 0; left[90:93, w - 2:] = 0
+    out.append(('edges', left))
+    return out
 
 
-def test_optimise_wave_strip_schedule_opt_in():
-    """k_optimise_ws.hip (MRCHIP_OPT_WS=1, not the default schedule): dense layers with dormant rows and wake-ups, sparse ones
-    with the short path, strips with hand-off, gray and RGB, n from 2 to 10 -- against the oracle, twice each (the hand-off
-    buffer's epoch)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MRCHIP_OPT_WS='1')
-    r = subprocess.run([sys.executable, '-c', WS_CHECK % {'root': root}], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert 'WS_BAD []' in r.stdout, r.stdout[-2000:]
+@pytest.mark.parametrize('c,n', [(3, 10), (3, 3), (1, 10), (3, 7), (1, 11), (3, 1), (1, 2)])
+def test_optimise_band_walkers_against_the_oracle(c, n, monkeypatch):
+    """Whole rows on one workgroup go through the band queue (optimise_band_kernel): rows without an unselected pixel are
+    copies, runs of rows separated by >= n of them are independent jobs that rebuild their sums from the image.  Gap
+    lengths n-1 / n / n+1, unselected pixels in the first / last row, no gaps, nothing / everything selected, bands
+    touching the left / right edge -- against the oracle, through the mask as given and through the invert flag."""
+    import ctypes as C
+    import mrc_oracle as O
+    from mrchip import optimiser
+    monkeypatch.setenv('MRCHIP_OPT_STRIPS', '0')           # (single calls would otherwise take column strips)
+    lib = _lib.load(); ctx = _lib.default_context()
+    rng = np.random.RandomState(100 * c + n)
+    for (h, w) in ((150, 1300), (97, 531)):
+        for name, mask in _band_masks(rng, h, w, n):
+            img = rng.randint(0, 256, (h, w, c) if c == 3 else (h, w)).astype(np.uint8)
+            exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+            got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
+            assert np.array_equal(got, exp), (name, h, w, int((got != exp).sum()), np.argwhere((got != exp).reshape(h, -1))[:4].tolist())
+            got2 = np.empty_like(img)
+            _lib.check(lib.mrchip_optimise(ctx.handle, _lib.ptr(np.ascontiguousarray(1 - mask)), _lib.ptr(img), _lib.ptr(got2), w, h, c, n, 1))
+            assert np.array_equal(got2, exp), (name, 'inverted', h, w, int((got2 != exp).sum()))
+
+
+def test_pages_through_the_band_walkers(monkeypatch):
+    """Full decomposition with whole-row workgroups forced (small batches take column strips by default): fg = one band,
+    bg = a band per group of text lines; text pages, a page without ink-free rows, an empty page."""
+    import mrc_oracle as O
+    from mrchip import mrc, synth
+    from PIL import Image
+    monkeypatch.setenv('MRCHIP_OPT_STRIPS', '0')
+    pages = [synth.synth_page(1000, 700, 3, seed=21, noise_sigma=6.0, line_div=20), synth.synth_page(640, 900, 1, seed=22, noise_sigma=3.0, line_div=40)]
+    rng = np.random.RandomState(3)
+    dense = rng.randint(0, 256, (300, 800, 3)).astype(np.uint8)             # ink in every row
+    pages.append((dense, []))
+    pages.append((np.full((200, 600, 3), 230, np.uint8), []))               # no ink at all
+    for img, hocr in pages:
+        pil = Image.fromarray(img)
+        got = list(mrc.create_mrc_hocr_components(pil, hocr, bg_downsample=3, denoise_mask='fast'))
+        exp = list(O.create_mrc_hocr_components(img, hocr, bg_downsample=3, denoise_mask='fast'))
+        for g, e, nm in zip(got, exp, ('mask', 'fg', 'bg')):
+            assert g.shape == e.shape and np.array_equal(g, e), (img.shape, nm, int((np.asarray(g) != np.asarray(e)).sum()))

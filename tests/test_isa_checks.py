@@ -47,11 +47,3 @@ def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
         rc, out = _scan(lst, key)
         assert rc == 0, (key, out[-1500:])
         assert _scratch_of(lst, key) == 0, key
-
-
-def test_wave_strip_requests_are_never_read_in_flight(tmp_path):
-    lst = _listing(tmp_path, 'k_optimise_ws')
-    key = 'optimise_ws_kernelILi3ELi0E'                 # RGB, the reference's two call sites
-    rc, out = _scan(lst, key)
-    assert rc == 0, out[-1500:]
-    assert _scratch_of(lst, key) == 0
