@@ -684,16 +684,27 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
             j.w = w; j.h = h;
             j.n = Lr ? 10 : 3;                                           // mrc.py:413/415, 447/449
             j.invert = Lr ? 1 : 0;                                       // mask_inv, mrc.py:439
+            // a layer that only feeds its thumbnail need not hold the rows between the bands of its walkers (they are image
+            // rows): the one-kernel thumbnail reads those from the image (honoured only if the band walkers take the launch)
+            j.skip_copy = (b->layer_small[Lr] && j.mbits &&
+                           thumbnail_reads_source_fused(b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl)) ? 1 : 0;
+            j.rowmap = nullptr;
             nmax = std::max(nmax, j.n);
         }
     }
     TRY(launch_optimise_jobs(ctx, s, hj, dj, nj, w, h, c, nmax, &b->opt_mail));      // (uploads the job records)
+    int first = 0;
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
-        if (b->layer_small[Lr])
+        if (b->layer_small[Lr]) {
+            // the launcher kept skip_copy where the band walkers ran: those layers hold their bands only
+            ThumbAlt ta = {b->img.pl, hj[first].rowmap};
+            const bool partial = hj[first].skip_copy && hj[first].rowmap;
             TRY(launch_thumbnail_plan(ctx, s, b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl, b->tables[Lr].p,
-                                      b->sc1[Lr].pl, b->sc2[Lr].pl, N));
+                                      b->sc1[Lr].pl, b->sc2[Lr].pl, N, partial ? &ta : nullptr));
+        }
         b->layer_done[Lr] = 1;
+        first += N;
     }
     return 0;
 }

@@ -141,7 +141,7 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     TRY(upload_2d(s, m.p, m.pitch, mask, w, w, h));
     TRY(upload_2d(s, i.p, i.pitch, img, w * channels, w * channels, h));
     OptJob job = {m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, n_size, invert_mask ? 1 : 0};
-    job.mbits = nullptr; job.mwpr = 0; job.rowflags = nullptr;
+    job.mbits = nullptr; job.mwpr = 0; job.rowflags = nullptr; job.skip_copy = 0; job.rowmap = nullptr;
     OptMail mail;                          // (declared before the launch: its buffers outlive the kernels, see below)
     TRY(launch_optimise_jobs(ctx, s, &job, jb.as<OptJob>(), 1, w, h, channels, n_size, &mail));
     TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));

@@ -625,7 +625,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
             }
         }
     };
-    if (band) copy_rows(band->c0, band->y0);
+    if (band && !J.skip_copy) copy_rows(band->c0, band->y0);
     if (yb1 > yb0) {
     // The sums in front of the band's first row yb0: FIR rows [yb0-1-n, yb0+n-1) (row y+n-1 enters, row y-n-1 leaves at
     // step y), IIR rows [yb0-n, yb0-1) -- image rows, the outputs there are copies -- and `prev` = row yb0-1, which step
@@ -947,7 +947,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     }
     store_row(yb1 - 1, prev);
     }
-    if (band) copy_rows(band->y1, band->c1);
+    if (band && !J.skip_copy) copy_rows(band->y1, band->c1);
 }
 
 // Rows of 4097..8160 columns: the same packed scheme with TWO groups of 4 columns per thread (columns
@@ -1253,6 +1253,8 @@ __global__ __launch_bounds__(1024) void opt_bands_kernel(const OptJob *jobs, Opt
     unsigned *fb = bb, *sb = bb + nw, *eb = bb + 2 * nw;
     const int t = threadIdx.x, NT = 1024;
     for (int i = t; i < 3 * nw; i += NT) bb[i] = 0;
+    if (J.rowmap)                                     // bit y: row y is written by a band (the others stay image rows)
+        for (int i = t; i < nw; i += NT) J.rowmap[i] = (J.rowflags && !J.invert) ? 0xffffffffu : 0u;
     if (t == 0) q[blockIdx.x] = OptBand{(int)blockIdx.x, 0, 0, 0, 0, {0, 0, 0}};
     __syncthreads();
     if (J.rowflags) {
@@ -1323,6 +1325,12 @@ __global__ __launch_bounds__(1024) void opt_bands_kernel(const OptJob *jobs, Opt
         const int pe = prev_bit(eb, y);                          // the band before ends there
         const int ns = next_bit(sb, e + 1);
         OptBand b = {(int)blockIdx.x, pe + 1, y, e + 1, ns >= h ? h : e + 1, {0, 0, 0}};
+        if (J.rowmap)
+            for (int r = y; r <= e;) {
+                const int lo = r & 31, cnt = min(32 - lo, e + 1 - r);
+                atomicOr(&J.rowmap[r >> 5], (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u)) << lo);
+                r += cnt;
+            }
         if ((b.y1 - b.y0) * 2 > h) q[blockIdx.x] = b;           // at most one such band per job
         else q[njobs + atomicAdd(&qctl[0], 1u)] = b;
     }
@@ -1547,6 +1555,14 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
             }
         }
     }
+    // skip_copy is honoured by the band walkers only: the records go up without it first (the strips may take the launch)
+    std::vector<int> want_skip(njobs);
+    bool any_skip = false;
+    for (int i = 0; i < njobs; i++) {
+        want_skip[i] = bands && h_jobs[i].skip_copy;
+        any_skip = any_skip || want_skip[i];
+        h_jobs[i].skip_copy = 0; h_jobs[i].rowmap = nullptr;
+    }
     HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
     {
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
@@ -1593,7 +1609,8 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     if (bands) {
         // queue: njobs front slots + one entry per band (a band and its gap take more than n_min rows) + control words
         const size_t cap = (size_t)njobs * (2 + h / (n_min + 1));
-        const size_t need = 256 + cap * sizeof(OptBand);
+        const size_t nw = (size_t)cdiv(h, 32);
+        const size_t need = 256 + cap * sizeof(OptBand) + (size_t)njobs * nw * sizeof(unsigned);
         if (mail->bandq_bytes < need) {
             HIP_TRY(hipStreamSynchronize(s));
             TRY(mail->bandq.alloc(ctx, need));
@@ -1601,6 +1618,13 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         }
         unsigned *qctl = mail->bandq.as<unsigned>();
         OptBand *q = reinterpret_cast<OptBand *>(mail->bandq.as<unsigned char>() + 256);
+        if (any_skip) {
+            // the row maps sit behind the queue (job k's at k * nw words): a consumer of consecutive jobs strides by nw
+            unsigned *maps = reinterpret_cast<unsigned *>(mail->bandq.as<unsigned char>() + 256 + cap * sizeof(OptBand));
+            for (int i = 0; i < njobs; i++)
+                if (want_skip[i]) { h_jobs[i].skip_copy = 1; h_jobs[i].rowmap = maps + (size_t)i * nw; }
+            HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
+        }
         HIP_TRY(hipMemsetAsync(qctl, 0, 8, s));
         LAUNCH(ctx, s, "optimise_bands", 0.0,
                hipLaunchKernelGGL(opt_bands_kernel, dim3(njobs), dim3(1024), 3 * cdiv(h, 32) * sizeof(unsigned), s, d_jobs, q, qctl, njobs));

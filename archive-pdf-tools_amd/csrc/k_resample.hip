@@ -604,7 +604,11 @@ __global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src
                                                                const int32_t *bias_h, const v4i *bt_h, int nout_v,
                                                                int ntiles_v, const int32_t *kbase_v, const int32_t *kend_v,
                                                                const int32_t *bias_v, const v4i *bt_v, int gx, int gy, int gz,
-                                                               int panel_w, int pws, int nb) {
+                                                               int panel_w, int pws, int nb, const uint8_t *alt, int apitch,
+                                                               size_t astride, const unsigned *rowmap, int rmwords) {
+    // alt / rowmap (optional): line y of page z comes from `src` where bit y of rowmap[z * rmwords ..] is set and from
+    // `alt` (same layout, its own pitch) where it is clear -- the bg layer of optimise's band walkers holds only the rows
+    // of its bands, every other row IS the image row (k_optimise.hip, OptBand): they are read from the image in place
     constexpr int NW = 8, TSTR = 272, RING = TSTR / 16;
     const int total = gx * gy * gz, per = (total + 7) >> 3;            // XCD-contiguous work order (see resize_mm_kernel)
     const int V = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -617,6 +621,12 @@ __global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src
     const int nn = lane & 15, kq = lane >> 4;
     src += (size_t)bz * sstride;
     dst += (size_t)bz * dstride;
+    unsigned *rmap = reinterpret_cast<unsigned *>(smem + 2 * 16 * pws + 128 * TSTR);      // the page's row map (rowmap != nullptr)
+    // (without a row map every bit is set and `alt` is `src`: ONE load site either way -- a branch around two would cost
+    // the compiler its count of the loads in flight, i.e. a full wait per group)
+    if (rowmap) alt += (size_t)bz * astride; else { alt = src; apitch = spitch; }
+    for (int i = tid; i < rmwords; i += 512) rmap[i] = rowmap ? rowmap[(size_t)bz * rmwords + i] : 0xffffffffu;
+    __syncthreads();
     const int tile0 = bx * NW;
     const int tvA = by * nb * RV, tvZ = min(tvA + nb * RV, ntiles_v);   // vertical tiles of this workgroup
     const int Lb = kbase_v[tvA];                                      // multiple of 16
@@ -656,7 +666,10 @@ __global__ __launch_bounds__(512) void resize_mm_fused_kernel(const uint8_t *src
     const int pofs = ld_line * pws + ld_chunk * 16;
     auto gload = [&](int g) -> v4i {                                  // 32-bit lane offset from the (scalar) page base
         const int line = min(Lb + g * 16 + ld_line, nlines - 1);
-        return *reinterpret_cast<const v4i_u1 *>(src + ((unsigned)line * (unsigned)spitch + colofs));
+        const bool own = (rmap[line >> 5] >> (line & 31)) & 1u;
+        const uint8_t *base = own ? src : alt;
+        const unsigned pit = own ? (unsigned)spitch : (unsigned)apitch;
+        return *reinterpret_cast<const v4i_u1 *>(base + ((unsigned)line * pit + colofs));
     };
     v4i stage[2];
     stage[0] = gload(0);
@@ -929,9 +942,21 @@ void ThumbPlan_scratch2_dims(const ThumbPlan &p, int *width_bytes, int *rows) {
 
 // d_tables: device copy of [bh_, kh_, bv_, kv_] in that order (int32), made by the caller.
 // scratch1: rw*rh*c per page (reduce output, if any); scratch2: ow*rh*c per page (horizontal pass output)
+// true when launch_thumbnail_plan will read `src` with the one-kernel matrix-core form (which can take rows from a second
+// plane: ThumbAlt)
+bool thumbnail_reads_source_fused(const ThumbPlan &p, Plane src, Plane dst) {
+    const bool red = p.fx > 1 || p.fy > 1;
+    return p.changed && !red && p.mm_ok && p.fuse_rv && (size_t)p.h * src.pitch < ((size_t)1 << 32) &&
+           (size_t)p.oh * dst.pitch < ((size_t)1 << 32);
+}
+
 int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
-                          const void *d_tables, Plane scratch1, Plane scratch2, int npages) {
+                          const void *d_tables, Plane scratch1, Plane scratch2, int npages, const ThumbAlt *ta) {
     const int c = p.c;
+    if (ta && !thumbnail_reads_source_fused(p, src, dst)) {
+        set_error("thumbnail: a row map needs the one-kernel form (thumbnail_reads_source_fused)");
+        return MRCHIP_E_ARG;
+    }
     if (!p.changed) {
         for (int i = 0; i < npages; i++)
             HIP_TRY(hipMemcpy2DAsync(dst.page(i), dst.pitch, src.page(i), src.pitch, (size_t)p.w * c, p.h,
@@ -972,7 +997,8 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
         int pws = pw + 16;
         if (((pws >> 4) & 1) == 0) pws += 16;
         const int rv = p.fuse_rv;
-        const size_t lds = (size_t)2 * 16 * pws + (size_t)128 * 272;
+        const int rmwords = cdiv(ch_, 32);
+        const size_t lds = (size_t)2 * 16 * pws + (size_t)128 * 272 + (size_t)rmwords * 4;
         const int gx = cdiv(H.ntiles, 8), nblk = cdiv(Vt.ntiles, rv);
         // blocks per workgroup: as long a run of lines as still leaves some twenty rounds of workgroups (768 run at a time)
         static const int nb_env = getenv("MRCHIP_FUSE_NB") ? atoi(getenv("MRCHIP_FUSE_NB")) : 0;
@@ -987,7 +1013,8 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
            hipLaunchKernelGGL((resize_mm_fused_kernel<KH, KV, RVV>), grid, dim3(512), lds, s, cur.p, cur.pitch, cur.stride,  \
                               ch_, cw * c, dst.p, dst.pitch, dst.stride, H.nout, H.ntiles, tptr(p.off_mm[0][0]),             \
                               tptr(p.off_mm[0][1]), bth, Vt.nout, Vt.ntiles, tptr(p.off_mm[1][0]), tptr(p.off_mmend[1]),     \
-                              tptr(p.off_mm[1][1]), btv, gx, gy, npages, pw, pws, nb))
+                              tptr(p.off_mm[1][1]), btv, gx, gy, npages, pw, pws, nb, ta ? ta->alt.p : nullptr,              \
+                              ta ? ta->alt.pitch : 0, ta ? ta->alt.stride : (size_t)0, ta ? ta->rowmap : nullptr, rmwords))
 #define MMF_RV(KH, KV) do { if (rv == 4) MMF_LAUNCH(KH, KV, 4); else if (rv == 2) MMF_LAUNCH(KH, KV, 2); else MMF_LAUNCH(KH, KV, 1); } while (0)
         if (H.KB == 1 && Vt.KB == 1) MMF_RV(1, 1);
         else if (H.KB == 1) MMF_RV(1, 2);

@@ -220,6 +220,10 @@ struct OptJob {
     // optional, with mbits: one byte per row, 1 = the row of the (uninverted) bit mask has a set pixel (the denoiser leaves
     // them); saves the band scan its pass over the bit rows
     const uint8_t *rowflags;
+    // band walkers only (launch_optimise_jobs clears it otherwise): do not copy the rows outside the bands into `out`;
+    // `rowmap` (set by the launcher, cdiv(h, 32) words) gets bit y = 1 for the rows that were written
+    int skip_copy;
+    unsigned *rowmap;
 };
 // hand-off buffer of the strip schedules (one per owner that may have a launch in flight: a batch, or a host-buffer
 // call).  The first 256 bytes of `buf` are unused padding; `err` is a page-locked host word the kernels set when a
@@ -298,8 +302,12 @@ size_t ThumbPlan_table_bytes(const ThumbPlan &p);          // == p.blob_.size():
 // per-page extent of the pass-to-pass scratch image (row-major ow*c x rh, or transposed + padded for the matrix-core path)
 void ThumbPlan_scratch2_dims(const ThumbPlan &p, int *width_bytes, int *rows);
 // dst: page i at dst + i*dstride (tight rows of dpitch bytes); scratch1/2 likewise with their strides
+// Rows of the source that live in another plane: row y of page i comes from `src` where bit y of rowmap[i * cdiv(h, 32) ..]
+// is set, from `alt` where it is clear (one-kernel matrix-core form only: thumbnail_reads_source_fused)
+struct ThumbAlt { Plane alt; const unsigned *rowmap; };
+bool thumbnail_reads_source_fused(const ThumbPlan &p, Plane src, Plane dst);
 int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Plane src, Plane dst,
-                          const void *d_tables, Plane scratch1, Plane scratch2, int npages);
+                          const void *d_tables, Plane scratch1, Plane scratch2, int npages, const ThumbAlt *ta = nullptr);
 size_t sigma_scratch_bytes(int w, int h, int kind);
 // one noise estimate = one job (a page's central crop, or one bool threshold of an hOCR box)
 struct SigJob {
