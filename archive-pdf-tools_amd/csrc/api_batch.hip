@@ -512,8 +512,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     // box commit write those rows alongside the mask bytes (a byte per lane more; a 16-bit OR per lane), and the separate
     // pass that re-read the whole byte mask to pack it is not run.
     const int wpr = cdiv(w, 32);
-    static const bool no_fuse = getenv("MRCHIP_FUSED_PACK") && atoi(getenv("MRCHIP_FUSED_PACK")) == 0;
-    const bool fuse_bits = denoise_fast && !no_fuse && w > 4 && h > 4 && wpr <= 512 && sauvola_writes_bits(w, h, b->window);
+    const bool fuse_bits = denoise_fast && w > 4 && h > 4 && wpr <= 512 && sauvola_writes_bits(w, h, b->window);
     b->commit_bits = fuse_bits;
     for (int i = 0; i < N; i++) {
         hj[i].src = thr_src.page(i); hj[i].src_pitch = thr_src.pitch;
@@ -533,7 +532,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     b->state = 4;
     b->packed_valid = 0;
     // the denoiser's bit rows are the final mask when its bit-sliced path ran (launch_denoise_batch)
-    b->bits_valid = denoise_fast && w > 4 && h > 4 && cdiv(w, 32) <= 512 && !getenv("MRCHIP_OPT_BYTEMASK");
+    b->bits_valid = denoise_fast && w > 4 && h > 4 && cdiv(w, 32) <= 512;
     return 0;
 }
 

@@ -201,100 +201,6 @@ __device__ __forceinline__ Row<KW> load_row(const unsigned *bits, int wpr, int y
     return r;
 }
 
-template <int KW>
-__global__ __launch_bounds__(64) void denoise_seq_kernel(unsigned *bits, int wpr, size_t bstride, int w, int h) {
-    // in place: row y is overwritten with its final value after rows y+1, y+2 have been read
-    const int lane = threadIdx.x;
-    bits += (size_t)blockIdx.x * bstride;      // one wave per page
-    constexpr int n = 2;
-    if (h <= 2 * n || w <= 2 * n) return;
-    // inner-column mask: columns [n, w-n)
-    unsigned inner[KW];
-#pragma unroll
-    for (int k = 0; k < KW; k++) {
-        int x0 = (lane * KW + k) * 32;
-        unsigned m = 0;
-        for (int i = 0; i < 32; i++) {
-            int x = x0 + i;
-            if (x >= n && x < w - n) m |= 1u << i;
-        }
-        inner[k] = m;
-    }
-    // rows 0,1 are final as they are
-    Row<KW> f2 = load_row<KW>(bits, wpr, 0, h, lane);
-    Row<KW> f1 = load_row<KW>(bits, wpr, 1, h, lane);
-    Row<KW> m0 = load_row<KW>(bits, wpr, 2, h, lane);
-    Row<KW> m1 = load_row<KW>(bits, wpr, 3, h, lane);
-    Row<KW> m2 = load_row<KW>(bits, wpr, 4, h, lane);
-    // prefetch ring for the incoming original rows
-    constexpr int PF = 4;
-    Row<KW> pf[PF];
-#pragma unroll
-    for (int i = 0; i < PF; i++) pf[i] = load_row<KW>(bits, wpr, 5 + i, h, lane);
-
-    Sat hf2[KW], hf1[KW], hm1[KW], hm2[KW];
-    h5<KW>(f2, lane, hf2);
-    h5<KW>(f1, lane, hf1);
-    h5<KW>(m1, lane, hm1);
-    h5<KW>(m2, lane, hm2);
-
-    for (int y = n; y < h - n; y++) {
-        // static part of the count: finals above, originals below, originals to the right
-        unsigned always[KW], t1[KW], t2[KW], fixed[KW], upd[KW];
-        {
-            unsigned L[KW], R[KW];
-            neighbours<KW>(m0, lane, L, R);
-#pragma unroll
-            for (int k = 0; k < KW; k++) {
-                Sat s = sat_add(sat_add(hf2[k], hf1[k]), sat_add(hm1[k], hm2[k]));
-                unsigned d = sh_p1(m0.w[k], R[k]), e = sh_p2(m0.w[k], R[k]);
-                Sat rr; rr.b0 = d ^ e; rr.b1 = d & e; rr.hi = 0;
-                s = sat_add(s, rr);
-                always[k] = s.hi;                        // static count >= 4
-                t1[k] = ~s.hi & s.b1 & s.b0;             // == 3: needs one more
-                t2[k] = ~s.hi & s.b1 & ~s.b0;            // == 2: needs both left neighbours
-                upd[k] = m0.w[k] & inner[k];
-                fixed[k] = m0.w[k] & ~inner[k];
-            }
-        }
-        // left-to-right recurrence: monotone iteration from the upper bound f = m0
-        Row<KW> f = m0;
-        for (;;) {
-            unsigned up = __shfl_up(f.w[KW - 1], 1);
-            if (lane == 0) up = 0;
-            unsigned changed = 0;
-            Row<KW> g;
-#pragma unroll
-            for (int k = 0; k < KW; k++) {
-                unsigned Lw = k > 0 ? f.w[k - 1] : up;
-                unsigned a = sh_m1(f.w[k], Lw), b = sh_m2(f.w[k], Lw);
-                unsigned nf = fixed[k] | (upd[k] & (always[k] | (t1[k] & (a | b)) | (t2[k] & a & b)));
-                changed |= nf ^ f.w[k];
-                g.w[k] = nf;
-            }
-            f = g;
-            if (!__any(changed != 0)) break;
-        }
-        // store the final row
-#pragma unroll
-        for (int k = 0; k < KW; k++) {
-            int j = lane * KW + k;
-            if (j < wpr) bits[(size_t)y * wpr + j] = f.w[k];
-        }
-        // advance the window
-#pragma unroll
-        for (int k = 0; k < KW; k++) { hf2[k] = hf1[k]; }
-        h5<KW>(f, lane, hf1);
-#pragma unroll
-        for (int k = 0; k < KW; k++) { hm1[k] = hm2[k]; }
-        m0 = m1; m1 = m2; m2 = pf[0];
-#pragma unroll
-        for (int i = 0; i + 1 < PF; i++) pf[i] = pf[i + 1];
-        pf[PF - 1] = load_row<KW>(bits, wpr, y + 3 + PF, h, lane);
-        h5<KW>(m2, lane, hm2);
-    }
-}
-
 // ---- the same solve, bands of rows in parallel ------------------------------------------------------------
 // Rows are sequential because row y needs the FINAL rows y-1, y-2.  But the final rows differ from the original
 // ones only where a pixel was dropped, and a dropped pixel matters to the rows below only if a pixel there sits on
@@ -487,14 +393,6 @@ __global__ __launch_bounds__(256) void denoise_jacobi_kernel(const uint8_t *orig
 // finished mask for the consumers (optimise reads it, unpack turns it into bytes)
 template <int KW>
 static int launch_seq(mrchip_ctx *ctx, hipStream_t s, unsigned *bits, int wpr, size_t bstride, int w, int h, int npages) {
-    static const int one_wave = getenv("MRCHIP_DENOISE_SEQ") ? 1 : 0;      // A/B knob: the one-wave-per-page solve
-    if (one_wave) {
-        HIP_TRY(hipMemcpy2DAsync(bits, bstride * 4, bits + (size_t)wpr * h, bstride * 4, (size_t)wpr * h * 4, npages,
-                                 hipMemcpyDeviceToDevice, s));
-        LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8 * npages,
-               hipLaunchKernelGGL((denoise_seq_kernel<KW>), dim3(npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
-        return 0;
-    }
     LAUNCH(ctx, s, "denoise_solve", 2.0 * w * h / 8 * npages,
            hipLaunchKernelGGL((denoise_band_kernel<KW>), dim3(cdiv(h, DN_BAND), npages), dim3(64), 0, s, bits, wpr, bstride, w, h));
     LAUNCH(ctx, s, "denoise_reconcile", 0.0,

@@ -424,11 +424,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     // carries FIR + IIR entries and ONE accumulator slides over the row: T(x+1) = T(x) + fir[x+n] + iir[x] - (fir+iir)[x-n]
     constexpr bool SUMROW = (NH == 1 && NCT >= 0 && NCT <= 7);
     // block sums in the pad slots: the window spans [x0-NCT, x0+NCT) = 2 + 4 + 4 | 4 + 4 + 2 columns for NCT = 10
-#ifdef MRCHIP_OPT_NO_BLOCKSUM
-    constexpr bool BLOCKSUM = false;
-#else
     constexpr bool BLOCKSUM = (NH == 2 && NCT == 10);
-#endif
     const uint8_t *__restrict__ mask = J.mask;
     const uint8_t *__restrict__ img = J.img;
     uint8_t *out = J.out;
@@ -1588,9 +1584,8 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     const size_t plds1 = (size_t)(pnent + pnent / 4 + 1) * ((c == 3) ? 16 : 8);
     // double-buffered LDS rows (row y publishes into buffer y & 1: one barrier per row instead of two) whenever twice the
     // rows fit: 256 page-layers of 4000 columns 6.06 -> 5.58 ms (round 1 measured no gain: the kernel then had more
-    // VALU work per row to hide the second barrier behind).  MRCHIP_OPT_DB=0 switches it off.
-    static const bool want_db = !(getenv("MRCHIP_OPT_DB") && atoi(getenv("MRCHIP_OPT_DB")) == 0);
-    const bool db = want_db && 2 * plds1 <= 160 * 1024;
+    // VALU work per row to hide the second barrier behind).
+    const bool db = 2 * plds1 <= 160 * 1024;
     const size_t plds = db ? 2 * plds1 : plds1;
 #define OPT_PACKED2(CC, NHH, MT, DBB, NAME)                                                             \
     do {                                                                                                \
@@ -1604,8 +1599,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     // wide rows: two groups of 4 columns per thread, LDS rows of one entry per column must still fit
     const int wwr = std::min(g.T * 8, (w + 3) & ~3), wnent = wwr + 2 * n_max;
     const size_t wlds = (size_t)(wnent + wnent / 4 + 1) * ((c == 3) ? 16 : 8);
-    static const bool no_wide = getenv("MRCHIP_OPT_NO_WIDE") != nullptr;
-    const bool wide_ok = !no_wide && wlds <= 160 * 1024;
+    const bool wide_ok = wlds <= 160 * 1024;
     if (bands) {
         // queue: njobs front slots + one entry per band (a band and its gap take more than n_min rows) + control words
         const size_t cap = (size_t)njobs * (2 + h / (n_min + 1));

@@ -1026,7 +1026,6 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
     }
     if (p.mm_ok) {
         // horizontal: lines = image rows -> scratch2 transposed [output byte][row]; vertical: lines = those -> dst
-        static const int qpw_env = getenv("MRCHIP_MM_QPW") ? atoi(getenv("MRCHIP_MM_QPW")) : 0;      // tuning knob
         // (quads of 64 lines per wave: chosen per pass below)
         const ThumbPlan::Mm *mm[2] = {&p.mmh, &p.mmv};
         for (int pass = 0; pass < 2; pass++) {
@@ -1034,9 +1033,9 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
             const Plane in = pass == 0 ? cur : scratch2, out = pass == 0 ? scratch2 : dst;
             const int nlines = pass == 0 ? ch_ : p.mmh.nout;
             // lines per wave: the horizontal pass (image rows are its lines) likes longer runs than the vertical one
-            const int qpw = qpw_env > 0 ? (pass == 0 ? qpw_env : 8) : (npages >= 16 ? (pass == 0 ? 16 : 8) : 2);
-            static const int wpb = getenv("MRCHIP_MM_WPB") ? atoi(getenv("MRCHIP_MM_WPB")) : 16;
-            static const int no_panel = getenv("MRCHIP_MM_NO_PANEL") ? 1 : 0;
+            const int qpw = npages >= 16 ? (pass == 0 ? 16 : 8) : 2;
+            constexpr int wpb = 16;
+            constexpr int no_panel = 0;
             // 8 tiles per workgroup where their panel fits the 512 loader lanes (16 lines x 32 chunks of 16 bytes): two
             // independent workgroups per CU instead of one of 16 waves (the kernel needs ~82 registers: 4-5 waves per
             // SIMD either way) overlap their barrier / load / MFMA phases -- 128 pages 1.64 + 0.58 -> 1.41 + 0.55 ms
@@ -1070,8 +1069,7 @@ int launch_thumbnail_plan(mrchip_ctx *ctx, hipStream_t s, const ThumbPlan &p, Pl
            hipLaunchKernelGGL((resize_mm_kernel<KBB, WW>), grid, dim3(64 * WW), 0, s, in.p, in.pitch, in.stride, nlines, \
                               out.p, out.pitch, out.stride, M.nout, M.ntiles, tptr(p.off_mm[pass][0]),                  \
                               tptr(p.off_mm[pass][1]), bt, qpw, pass == 0 ? 1 : 0, gx, gy, npages))
-            if (M.KB == 1) { if (wpb == 4) MM_LAUNCH(1, 4); else if (wpb == 8) MM_LAUNCH(1, 8); else MM_LAUNCH(1, 16); }
-            else { if (wpb == 4) MM_LAUNCH(2, 4); else if (wpb == 8) MM_LAUNCH(2, 8); else MM_LAUNCH(2, 16); }
+            if (M.KB == 1) MM_LAUNCH(1, 16); else MM_LAUNCH(2, 16);
 #undef MM_LAUNCH
         }
         return 0;

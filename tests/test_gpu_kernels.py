@@ -327,3 +327,36 @@ def test_pages_through_the_band_walkers(monkeypatch):
         exp = list(O.create_mrc_hocr_components(img, hocr, bg_downsample=3, denoise_mask='fast'))
         for g, e, nm in zip(got, exp, ('mask', 'fg', 'bg')):
             assert g.shape == e.shape and np.array_equal(g, e), (img.shape, nm, int((np.asarray(g) != np.asarray(e)).sum()))
+
+
+NOBANDS_CHECK = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, 'archive-pdf-tools_amd')); sys.path.insert(0, os.path.join(%(root)r, 'oracle'))
+import mrc_oracle as O
+from mrchip import optimiser
+rng = np.random.RandomState(5)
+bad = []
+for (h, w, c, n, dens) in [(120, 1300, 3, 10, 0.93), (90, 700, 1, 3, 0.07), (64, 2100, 3, 7, 0.5)]:
+    img = rng.randint(0, 256, (h, w, c) if c == 3 else (h, w)).astype(np.uint8)
+    mask = (rng.rand(h, w) < dens).astype(np.uint8)
+    mask[20:45] = 1
+    exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+    got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
+    if not np.array_equal(exp, got):
+        bad.append((h, w, c, n, int((exp != got).sum())))
+print('NOBANDS_BAD', bad)
+'''
+
+
+def test_optimise_whole_page_workgroups_without_the_band_queue():
+    """MRCHIP_OPT_BANDS=0 (read once per process): one workgroup per page-layer walking every row (optimise_packed_kernel),
+    the schedule the band walkers replaced; it stays the fallback for n_size 0 and pages of 65536 rows or more."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRCHIP_OPT_BANDS='0', MRCHIP_OPT_STRIPS='0')
+    r = subprocess.run([sys.executable, '-c', NOBANDS_CHECK % {'root': root}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'NOBANDS_BAD []' in r.stdout, r.stdout[-2000:]
