@@ -142,10 +142,11 @@ MRCHIP_EXPORT int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const ui
     TRY(upload_2d(s, i.p, i.pitch, img, w * channels, w * channels, h));
     OptJob job = {m.p, m.pitch, i.p, i.pitch, o.p, o.pitch, w, h, n_size, invert_mask ? 1 : 0};
     job.mbits = nullptr; job.mwpr = 0; job.rowflags = nullptr; job.skip_copy = 0; job.rowmap = nullptr;
-    OptMail mail;                          // (declared before the launch: its buffers outlive the kernels, see below)
+    if (!ctx->host_mail) ctx->host_mail = new OptMail;       // lives with the context (hand-off buffers, queue, error word)
+    OptMail &mail = *ctx->host_mail;
     TRY(launch_optimise_jobs(ctx, s, &job, jb.as<OptJob>(), 1, w, h, channels, n_size, &mail));
     TRY(download_2d(s, out, w * channels, o.p, o.pitch, w * channels, h));
-    HIP_TRY(hipStreamSynchronize(s));      // `job` and `mail` live on this stack frame
+    HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
     return optmail_check(&mail);
 }
 

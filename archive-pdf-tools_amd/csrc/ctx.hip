@@ -195,6 +195,8 @@ MRCHIP_EXPORT void mrchip_destroy(mrchip_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    delete ctx->host_mail;                 // (before the blocks go: its DevBufs return to the allocator first)
+    ctx->host_mail = nullptr;
     for (auto &b : ctx->blocks)
         if (b.base) (void)hipFree(b.base);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

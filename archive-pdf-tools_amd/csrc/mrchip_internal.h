@@ -73,6 +73,7 @@ struct ProfPending {
     hipEvent_t a, b;
 };
 
+struct OptMail;
 constexpr int NSTREAMS = 4;
 constexpr int MAX_GRID_Z = 65535;      // hipDeviceProp_t::maxGridSize[2] (and [1])
 
@@ -94,6 +95,9 @@ struct mrchip_ctx {
     // while an entry point that enqueues asynchronous work on scratch buffers is running: the stream
     // its DevBufs must wait for before they go back to the allocator (error paths return early)
     hipStream_t scratch_sync = nullptr;
+    // hand-off buffers / error word of mrchip_optimise's launches (one per context: a per-call object would allocate and free
+    // page-locked memory -- two device synchronisations -- on every call)
+    mrchip::OptMail *host_mail = nullptr;
     int cus = 0;
     size_t hbm = 0;
     char name[128] = {};

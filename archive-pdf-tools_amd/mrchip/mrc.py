@@ -746,14 +746,22 @@ _STAGE_KERNELS = {
 
 class _StageClock:
     """Per-stage seconds for timing_data: the GPU time of the kernels behind each key, from the library's HIP-event
-    profile (mrchip_prof_*), taken as differences of the running totals so that a caller's own profiling is left alone."""
+    profile (mrchip_prof_*), taken as differences of the running totals so that a caller's own profiling is left alone.
+
+    The profile is per context: the figures are this page's only while nothing else runs on the context (two
+    interleaved generators with timing_data, or a decompose_stream on another thread of the same context, would book each
+    other's kernels).  Enabling is reference-counted per context, so the first generator to finish does not switch the
+    profile off under a second one, and a caller who enabled profiling himself keeps it."""
 
     def __init__(self, ctx, on):
         self.ctx, self.on = ctx, on
-        self.was = getattr(ctx, 'prof_on', False)
         if on:
-            if not self.was:
-                ctx.prof_enable(True)
+            users = getattr(ctx, '_stage_clock_users', 0)
+            if users == 0:
+                ctx._stage_clock_was_on = bool(getattr(ctx, 'prof_on', False))
+                if not ctx._stage_clock_was_on:
+                    ctx.prof_enable(True)
+            ctx._stage_clock_users = users + 1
             self.last = ctx.prof_report()
 
     def lap(self):
@@ -768,8 +776,11 @@ class _StageClock:
         return out
 
     def close(self):
-        if self.on and not self.was:
-            self.ctx.prof_enable(False)
+        if self.on:
+            self.on = False
+            self.ctx._stage_clock_users -= 1
+            if self.ctx._stage_clock_users == 0 and not self.ctx._stage_clock_was_on:
+                self.ctx.prof_enable(False)
 
 
 def _book(timing_data, wall, main_key, entries):

@@ -58,7 +58,7 @@ def note(*a):
 
 
 while time.time() - t0 < budget:
-    what = rng.randint(14)
+    what = rng.randint(17)
     if what == 0:       # sauvola
         h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
         ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
@@ -237,7 +237,81 @@ while time.time() - t0 < budget:
         exp = m0 | O.threshold_image(src, dpi)
         assert np.array_equal(got, exp), ('threshold_mask', h, w, dpi)
         tick('threshold_mask')
-    else:               # whole pages
+    elif what == 14:    # optimise, band walkers (whole rows forced): unselected pixels in runs of rows with gaps around n_size
+        h, w = int(rng.randint(30, 400)), int(rng.randint(8, 1300))
+        c = int(rng.choice([1, 3])); n = int(rng.choice([1, 2, 3, 5, 7, 10, 11]))
+        img = rnd_img(h, w, c)
+        mask = np.ones((h, w), np.uint8)
+        y = int(rng.randint(0, 3 * n + 2)) if rng.rand() < 0.8 else 0
+        while y < h:
+            run = int(rng.randint(1, 12))
+            for yy in range(y, min(h, y + run)):
+                if rng.rand() < 0.7:
+                    mask[yy] = (rng.rand(w) >= rng.choice([0.01, 0.2, 0.8])).astype(np.uint8)
+            y += run + int(rng.choice([n - 1, n, n + 1, 2 * n + 1, 0, 40]))
+        if rng.rand() < 0.2: mask[h - 1, int(rng.randint(w))] = 0
+        inv = bool(rng.rand() < 0.5)
+        note('optimise_bands', h, w, c, n, inv)
+        os.environ['MRCHIP_OPT_STRIPS'] = '0'
+        try:
+            got = np.empty_like(img)
+            m_arg = np.ascontiguousarray(1 - mask) if inv else mask
+            _lib.check(lib.mrchip_optimise(ctx.handle, _lib.ptr(m_arg), _lib.ptr(img), _lib.ptr(got), w, h, c, n, 1 if inv else 0))
+        finally:
+            del os.environ['MRCHIP_OPT_STRIPS']
+        exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+        assert np.array_equal(got, exp), ('optimise_bands', h, w, c, n, inv)
+        tick('optimise_bands')
+    elif what == 15:    # adversarial pages: black scanner border, saturated / constant regions, an inverted block, two-level areas
+        h, w = int(rng.randint(60, 700)), int(rng.randint(60, 1100)); c = int(rng.choice([1, 3]))
+        img, hocr = synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 6, 12])),
+                                     line_div=int(rng.choice([8, 14, 30])))
+        img = img.copy()
+        ops = rng.rand(6)
+        if ops[0] < 0.5:
+            bw = int(rng.randint(1, 41)); img[:bw] = 3; img[-bw:] = 0; img[:, :bw] = 5; img[:, -bw:] = 2
+        if ops[1] < 0.5:
+            y0, x0 = int(rng.randint(h // 2)), int(rng.randint(w // 2)); img[y0:y0 + h // 3, x0:x0 + w // 3] = 255 - img[y0:y0 + h // 3, x0:x0 + w // 3]
+        if ops[2] < 0.4:
+            y0 = int(rng.randint(h - 8)); img[y0:y0 + int(rng.randint(1, 60))] = int(rng.choice([0, 255, 128]))
+        if ops[3] < 0.4:
+            yy, xx = np.mgrid[0:h, 0:w]; chk = ((yy // 5 + xx // 3) % 2 == 0); sel = (yy > h // 2) & (xx > w // 2) & chk
+            img[sel] = 0; img[(yy > h // 2) & (xx > w // 2) & ~chk] = 255
+        if ops[4] < 0.3:
+            img[:, int(rng.randint(w))] = 20                   # a rule down the page: ink in every row
+        kw = dict(dpi=rng.choice([None, 200, 400]), bg_downsample=rng.choice([None, 3]), fg_downsample=rng.choice([None, 2]))
+        kw = {k: (None if v is None else int(v)) for k, v in kw.items()}
+        whole = bool(rng.rand() < 0.5)
+        note('adversarial_page', h, w, c, kw, whole, ops.tolist())
+        if whole: os.environ['MRCHIP_OPT_STRIPS'] = '0'
+        try:
+            g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            for i in range(3):
+                a, b = next(g), next(e)
+                assert a.shape == b.shape and np.array_equal(a, b), ('adversarial_page', h, w, c, kw, i)
+        finally:
+            os.environ.pop('MRCHIP_OPT_STRIPS', None)
+        tick('adversarial_page')
+    elif what == 16:    # batches through the band walkers + the thumbnail that reads gap rows from the image
+        h, w = int(rng.randint(60, 420)), int(rng.randint(120, 900)); c = int(rng.choice([1, 3])); npg = int(rng.randint(1, 5))
+        pages = [synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 4, 9])),
+                                  line_div=int(rng.choice([6, 12, 24]))) for _ in range(npg)]
+        kw = dict(dpi=rng.choice([None, 150]), bg_downsample=rng.choice([None, 2, 3, 4]), fg_downsample=rng.choice([None, 2, 3]))
+        kw = {k: (None if v is None else int(v)) for k, v in kw.items()}
+        note('batch_bands', h, w, c, npg, kw)
+        os.environ['MRCHIP_OPT_STRIPS'] = '0'
+        try:
+            res = mrc.decompose_pages([p[0] for p in pages], [p[1] for p in pages], denoise_mask='fast', **kw)
+        finally:
+            del os.environ['MRCHIP_OPT_STRIPS']
+        for (img, hocr), (mask, fg, bg) in zip(pages, res):
+            e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            for a in (mask, fg, bg):
+                b = next(e)
+                assert a.shape == b.shape and np.array_equal(a, b), ('batch_bands', h, w, c, kw)
+        tick('batch_bands')
+    else:               # whole pages (what == 5)
         h, w = int(rng.randint(20, 900)), int(rng.randint(20, 1300)); c = int(rng.choice([1, 3]))
         img, hocr = synth.synth_page(w, h, c, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 6, 12, 25])),
                                      line_div=int(rng.choice([6, 10, 20, 40])))
