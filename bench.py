@@ -172,12 +172,17 @@ def _profile_kernel(kernels, name):
     return max(hits, key=lambda kv: kv[1].get('launches', 0))[1] if hits else None
 
 
+PROFILE_ROUND = 'r04'
+
+
 def _pick_profile(kind, config, inflight):
     """The newest committed profiles/<round>_*<kind>_summary.json whose bench command ran THIS configuration (--config)
     with this many batches in flight; None when there is none -- numbers of another workload are not attached."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_summary.json' % kind))):
+    # (profiles of THIS round only: the kernels of earlier rounds are different code under similar names)
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_*%s_summary.json' % kind)) +
+                    glob.glob(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_%s_summary.json' % kind))):
         try:
             d = json.load(open(f))
         except Exception:
@@ -189,7 +194,9 @@ def _pick_profile(kind, config, inflight):
         cfgname = opt('--config', 'c2')
         infl = int(opt('--inflight', CONFIGS.get(cfgname, {}).get('inflight', 1)))
         if cfgname == config and infl == inflight:
-            best = (f, d)              # sorted: later rounds win
+            best = (f, d)
+        elif cfgname == config and kind == 'valu' and best is None:
+            best = (f, d)              # instruction counts per pixel do not depend on how many batches are in flight
     return best
 
 
