@@ -51,12 +51,6 @@ struct mrchip_batch {
     DevBuf sig_scratch;  size_t sig_stride = 0;
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
     OptMail opt_mail;                 // hand-off granules of optimise's column-strip schedule, queue of the band walkers
-    // Large batches run the fg layers (one 3000-row chain per page: ~4.7 ms whatever the chip does beside it) on a stream
-    // of their own, so that the bg layers (independent bands: done in a third of that) and the bg thumbnail fill the other
-    // half of the chip meanwhile instead of queueing behind the fg chains (run_layers)
-    hipStream_t s_fg = nullptr;
-    hipEvent_t ev_mask = nullptr, ev_fg = nullptr;
-    OptMail opt_mail_fg;
     std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
     hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
     int bits_valid = 0;                       // dn_bits holds the finished masks at 1 bpp (fast denoise ran)
@@ -156,9 +150,6 @@ MRCHIP_EXPORT void mrchip_batch_destroy(mrchip_batch *b) {
     (void)hipStreamSynchronize(b->s);
     if (b->hctrl) (void)hipHostFree(b->hctrl);
     if (b->box_ev) (void)hipEventDestroy(b->box_ev);
-    if (b->s_fg) { (void)hipStreamSynchronize(b->s_fg); (void)hipStreamDestroy(b->s_fg); }
-    if (b->ev_mask) (void)hipEventDestroy(b->ev_mask);
-    if (b->ev_fg) (void)hipEventDestroy(b->ev_fg);
     delete b;
 }
 
@@ -712,25 +703,6 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
         b->layer_done[Lr] = 1;
         return 0;
     };
-    const int cus = ctx->cus > 0 ? ctx->cus : 256;
-    if (do_fg && do_bg && N * 4 > cus && w <= 4096) {
-        // fg first, on its own stream behind the mask: N whole-row workgroups take N CUs for the length of the chain
-        if (!b->s_fg) {
-            HIP_TRY(hipStreamCreateWithFlags(&b->s_fg, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_mask, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_fg, hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(b->ev_mask, s));
-        HIP_TRY(hipStreamWaitEvent(b->s_fg, b->ev_mask, 0));
-        TRY(launch_optimise_jobs(ctx, b->s_fg, hj, dj, N, w, h, c, 3, &b->opt_mail_fg, true));
-        TRY(thumb(0, 0, b->s_fg));
-        HIP_TRY(hipEventRecord(b->ev_fg, b->s_fg));
-        // bg: bands on whatever is free, then its thumbnail, beside the fg chains
-        TRY(launch_optimise_jobs(ctx, s, hj + N, dj + N, N, w, h, c, 10, &b->opt_mail, true));
-        TRY(thumb(1, N, s));
-        HIP_TRY(hipStreamWaitEvent(s, b->ev_fg, 0));          // the batch's stream is done when both layers are
-        return 0;
-    }
     TRY(launch_optimise_jobs(ctx, s, hj, dj, nj, w, h, c, nmax, &b->opt_mail));      // (uploads the job records)
     int first = 0;
     for (int Lr = 0; Lr < 2; Lr++) {
@@ -784,7 +756,7 @@ static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *ou
     if (wait) {
         HIP_TRY(hipStreamSynchronize(b->s));
         TRY(optmail_check(&b->opt_mail));          // a strip hand-off of optimise timed out: the layer is not valid
-        TRY(optmail_check(&b->opt_mail_fg));
+
     }
     return 0;
 }
@@ -792,7 +764,6 @@ static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *ou
 MRCHIP_EXPORT int mrchip_batch_sync(mrchip_batch *b) {
     CHECK_B(b);
     HIP_TRY(hipStreamSynchronize(b->s));
-    TRY(optmail_check(&b->opt_mail_fg));
     return optmail_check(&b->opt_mail);
 }
 

@@ -1508,7 +1508,7 @@ int optmail_check(OptMail *mail) {
 }
 
 int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
-                         int n_max, OptMail *mail, bool whole_rows) {
+                         int n_max, OptMail *mail) {
     if (c != 1 && c != 3) { set_error("optimise: channels must be 1 or 3"); return MRCHIP_E_ARG; }
     if (w <= 0 || h <= 0 || njobs <= 0) return 0;
     if (!mail) { set_error("optimise: no hand-off buffer"); return MRCHIP_E_ARG; }
@@ -1560,7 +1560,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         h_jobs[i].skip_copy = 0; h_jobs[i].rowmap = nullptr;
     }
     HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
-    if (!(whole_rows && bands)) {
+    {
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
         if (st != 0) return st < 0 ? st : 0;
     }

@@ -251,9 +251,8 @@ struct OptMail {
 int optmail_check(OptMail *mail);
 // h_jobs: host copy of the job records (the launcher fills the schedule's fields and uploads them to d_jobs on `s`;
 // it must stay valid until the copy has run)
-// whole_rows: do not cut the page-layers into column strips even if the launch leaves CUs idle (the caller fills them)
 int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob *d_jobs, int njobs, int w, int h, int c,
-                         int n_max, OptMail *mail, bool whole_rows = false);
+                         int n_max, OptMail *mail);
 // bytes != 0 -> 1 bit per pixel, LSB first, wpr dwords per row (the denoiser's rows)
 int launch_pack_bits(mrchip_ctx *ctx, hipStream_t s, const uint8_t *mask, int pitch, int w, int h, unsigned *bits, int wpr);
 
