@@ -102,12 +102,9 @@ __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> 
     const int w = J.w, h = J.h, pitch = J.pitch;
     constexpr bool AS_BOOL = sizeof(T) == 8;               // the float64 path is PyWavelets' treatment of bool arrays
     const int w2 = (w + 3) / 2, h2 = (h + 3) / 2;
-    // four copies of the first digit's histogram, lane l adds to copy l & 3: the |dd| of a page fall into a handful of bins,
-    // and 64 lanes adding to one LDS word serialise (r03_pmc_table.txt: 65-74 % of this kernel's LDS cycles were conflicts)
-    __shared__ unsigned lh4[4][NBIN];
-    for (int i = threadIdx.x; i < 4 * NBIN; i += 256) (&lh4[0][0])[i] = 0;
+    __shared__ unsigned lh[NBIN];
+    for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
-    unsigned *lh = lh4[threadIdx.x & 3];
     const int m0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // first of the lane's 4 columns of dd
     const uint8_t *src = J.src;
     T *dd = reinterpret_cast<T *>(J.scratch + dd_off);
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> 
     __syncthreads();
     SelState *st = reinterpret_cast<SelState *>(J.scratch);
     for (int i = threadIdx.x; i < NBIN; i += 256) {
-        const unsigned c = lh4[0][i] + lh4[1][i] + lh4[2][i] + lh4[3][i];
+        const unsigned c = lh[i];
         if (c) { atomicAdd(&st->hist[0][i], c); atomicAdd(&st->hist[1][i], c); }
     }
 }
