@@ -347,7 +347,9 @@ def main():
             sys.exit(7)
         if rank == 0:
             print(json.dumps({'dryrun': True, 'n_gpus': world, 'ranks': ids, 'spawned': bool(os.environ.get('MRCHIP_BENCH_SPAWNED'))}))
+            sys.stdout.flush()
         comm.barrier()
+        tdist.destroy_process_group()       # (a rank that exits with gloo's threads alive aborts now and then: "terminate called ...")
         return
 
     # the CPU baseline forks worker processes: before the first GPU call of this process
