@@ -50,7 +50,7 @@ struct mrchip_batch {
     DevBuf gtmp;  int gtmp_pitch = 0;  size_t gtmp_stride = 0;     // float32 scratch of the blur
     DevBuf sig_scratch;  size_t sig_stride = 0;
     DevBuf box_sig_scratch, dn_bits, ctrl, thA, thB, tables[2];
-    OptMail opt_mail;                 // hand-off granules of optimise's column-strip schedule, queue of the band walkers
+    OptMail opt_mail;                 // hand-off granules of optimise's column-strip schedule
     std::vector<int> need;  std::vector<double> ratio, inv_ratio;      // box decisions in flight (mask_finish)
     hipEvent_t box_ev = nullptr;  size_t box_sig_cap = 0;
     int bits_valid = 0;                       // dn_bits holds the finished masks at 1 bpp (fast denoise ran)
@@ -691,23 +691,18 @@ static int run_layers(mrchip_batch *b, bool do_fg, bool do_bg, double fg_ds, dou
             nmax = std::max(nmax, j.n);
         }
     }
-    // thumbnail of layer Lr (jobs first .. first + N - 1) on stream `st`
-    auto thumb = [&](int Lr, int first, hipStream_t st) -> int {
-        if (b->layer_small[Lr]) {
-            // the launcher kept skip_copy where the band walkers ran: those layers hold their bands only
-            ThumbAlt ta = {b->img.pl, hj[first].rowmap};
-            const bool partial = hj[first].skip_copy && hj[first].rowmap;
-            TRY(launch_thumbnail_plan(ctx, st, b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl, b->tables[Lr].p,
-                                      b->sc1[Lr].pl, b->sc2[Lr].pl, N, partial ? &ta : nullptr));
-        }
-        b->layer_done[Lr] = 1;
-        return 0;
-    };
     TRY(launch_optimise_jobs(ctx, s, hj, dj, nj, w, h, c, nmax, &b->opt_mail));      // (uploads the job records)
     int first = 0;
     for (int Lr = 0; Lr < 2; Lr++) {
         if (!(Lr == 0 ? do_fg : do_bg)) continue;
-        TRY(thumb(Lr, first, s));
+        if (b->layer_small[Lr]) {
+            // the launcher kept skip_copy where the band walkers ran: those layers hold their bands only
+            ThumbAlt ta = {b->img.pl, hj[first].rowmap};
+            const bool partial = hj[first].skip_copy && hj[first].rowmap;
+            TRY(launch_thumbnail_plan(ctx, s, b->plan[Lr], b->layer[Lr].pl, b->small[Lr].pl, b->tables[Lr].p,
+                                      b->sc1[Lr].pl, b->sc2[Lr].pl, N, partial ? &ta : nullptr));
+        }
+        b->layer_done[Lr] = 1;
         first += N;
     }
     return 0;
@@ -756,7 +751,6 @@ static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *ou
     if (wait) {
         HIP_TRY(hipStreamSynchronize(b->s));
         TRY(optmail_check(&b->opt_mail));          // a strip hand-off of optimise timed out: the layer is not valid
-
     }
     return 0;
 }

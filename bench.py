@@ -103,6 +103,32 @@ def _cpu_worker(args):
     return done, time.time() - t0
 
 
+def host_memory_budget():
+    """Bytes this process tree may still take: the smaller of the host's MemAvailable and what the memory cgroup of the
+    container leaves (v2 memory.max / v1 limit_in_bytes minus the current usage).  /proc/meminfo shows the HOST's
+    memory inside a container: sizing worker pools from it alone can run a cgroup out of memory -- which is what most
+    likely took two GPU boxes down in round 4 (`bench.py --config c5` with the CPU baseline: DESIGN.md 6)."""
+    avail = 32 << 30
+    try:
+        with open('/proc/meminfo') as f:
+            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
+    except Exception:
+        pass
+    for lim, use in (('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory.current'),
+                     ('/sys/fs/cgroup/memory/memory.limit_in_bytes', '/sys/fs/cgroup/memory/memory.usage_in_bytes')):
+        try:
+            with open(lim) as f:
+                v = f.read().strip()
+            if v and v != 'max':
+                with open(use) as f:
+                    used = int(f.read().strip())
+                if int(v) < (1 << 60):
+                    avail = min(avail, max(0, int(v) - used))
+        except Exception:
+            continue
+    return avail
+
+
 def cpu_baseline(cfg, seconds=12.0):
     """The oracle (C restatement of the reference, kind "port") decomposing pages of this workload on every host core:
     one worker PROCESS per core (each synthesises its own page, then decomposes it in a loop for `seconds`), bounded by
@@ -110,13 +136,11 @@ def cpu_baseline(cfg, seconds=12.0):
     per-core figure."""
     import multiprocessing as mp
     ncpu = ncpus()
+    # measured peak RSS of a worker: 0.83 GB (4000x3000 RGB), 1.05 (3300x4600 RGB), 3.2 (8000x6000 RGB); 1.2 GB per 36 MB of
+    # page is the allowance.  A quarter of what the container may still take, and never more than 128 GB in all.
     per_worker = 1.2e9 * (cfg['w'] * cfg['h'] * cfg['c']) / 36e6
-    try:
-        with open('/proc/meminfo') as f:
-            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
-    except Exception:
-        avail = 32 << 30
-    workers = int(max(1, min(ncpu, 0.5 * avail / per_worker)))
+    budget = min(0.25 * host_memory_budget(), 128e9)
+    workers = int(max(1, min(ncpu, budget / per_worker)))
     ctx = mp.get_context('fork')
     with ctx.Pool(1) as pool:
         n1, dt1 = pool.map(_cpu_worker, [(0, seconds / 2, cfg)])[0]
@@ -317,6 +341,7 @@ def main():
     ap.add_argument('--distinct', type=int, default=None, help='distinct synthetic pages per GPU, cycled through the batch')
     ap.add_argument('--e2e-pages', type=int, default=512, help='pages per GPU pushed through the streaming pipeline (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', action='store_true', help='time the CPU port on this configuration too (default: only on c2, the workload the metric is quoted on)')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (profiling runs)')
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
@@ -354,7 +379,7 @@ def main():
 
     # the CPU baseline forks worker processes: before the first GPU call of this process
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_extras:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_extras and (a.config == 'c2' or a.cpu_baseline):
         cpu = cpu_baseline(cfg)
 
     from mrchip import _lib, mrc, synth
@@ -780,7 +805,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     try:
         import psutil
         # one pass of distinct arrays is alive at a time on every rank of the node: a quarter of the free memory between them
-        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, psutil.virtual_memory().available * 0.25 // (max(world, 1) * page_bytes))))
+        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, min(psutil.virtual_memory().available, host_memory_budget()) * 0.2 // (max(world, 1) * page_bytes))))
     except Exception:      # noqa: BLE001
         n_fresh = min(n_pages, 128)
     if os.environ.get('MRCHIP_BENCH_FRESH', '1') != '0':
@@ -797,7 +822,8 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
         keep.clear()
 
         import threading
-        RING = E2E_BATCH * (E2E_SLOTS + 12)
+        # page-locked ring: at most 16 GB and a tenth of what the container may still take (8000x6000 pages: 144 MB each)
+        RING = int(max(E2E_BATCH * (E2E_SLOTS + 2), min(E2E_BATCH * (E2E_SLOTS + 12), min(16e9, 0.1 * host_memory_budget()) // page_bytes)))
         RING_THREADS = 4
         import ctypes
         ring = [ctx.pinned_empty(host_pages[0][0].shape) for _ in range(RING)]
