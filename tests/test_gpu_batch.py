@@ -114,3 +114,39 @@ def test_decompose_pages_groups_mixed_sizes_and_modes():
         for a in got:
             b = next(e)
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('c,bg_ds,fg_ds', [(3, 3, None), (1, None, None), (3, 2, 2)])
+def test_large_batch_takes_the_band_queue(c, bg_ds, fg_ds):
+    """More page-layers than half the CUs: optimise runs on the band walkers (a persistent workgroup per CU on a
+    device-built queue) instead of column strips -- the schedule of the 128-page bench batches, here with 132 small pages
+    (six distinct ones, with and without ink-free gaps) against the oracle.  bg_downsample set: the bg layer holds its
+    bands only and the one-kernel thumbnail reads the other rows from the image."""
+    ctx = _lib.default_context()
+    w, h, n = 320, 240, 132
+    distinct = [synth.synth_page(w, h, c, seed=900 + i, noise_sigma=ns, line_div=ld)
+                for i, (ns, ld) in enumerate([(6.0, 12), (0.0, 20), (12.0, 8), (3.0, 30)])]
+    rng = np.random.RandomState(4)
+    dense = rng.randint(0, 256, (h, w, 3) if c == 3 else (h, w)).astype(np.uint8)          # ink in every row: one band
+    blank = np.full((h, w, 3) if c == 3 else (h, w), 231, np.uint8)                        # no ink: a layer of copies
+    distinct += [(dense, []), (blank, [])]
+    bt = mrc.Batch(ctx, n, w, h, c)
+    for i in range(n):
+        img, hocr = distinct[i % len(distinct)]
+        bt.upload(i, img)
+        bt.set_boxes(i, mrc.hocr_boxes(hocr, w, h))
+    bt.mask_begin(51)
+    bt.mask_finish(bt.sigmas(), True)
+    fg_size, bg_size, _ = bt.layers(fg_ds, bg_ds)
+    exp = []
+    for img, hocr in distinct:
+        g = O.create_mrc_hocr_components(img, hocr, bg_downsample=bg_ds, fg_downsample=fg_ds, denoise_mask='fast')
+        exp.append((next(g).copy(), next(g), next(g)))
+    for i in list(range(12)) + [63, 64, 65, 126, 127, 128, 131]:
+        em, ef, eb = exp[i % len(distinct)]
+        assert np.array_equal(bt.download_mask(i), em), i
+        fg = bt.download_layer(i, 0, fg_size)
+        bg = bt.download_layer(i, 1, bg_size)
+        assert fg.shape == ef.shape and np.array_equal(fg, ef), (i, int((fg != ef).sum()))
+        assert bg.shape == eb.shape and np.array_equal(bg, eb), (i, int((bg != eb).sum()))
+    bt.close()
