@@ -126,10 +126,10 @@ def test_large_batch_takes_the_band_queue(c, bg_ds, fg_ds):
     w, h, n = 320, 240, 132
     distinct = [synth.synth_page(w, h, c, seed=900 + i, noise_sigma=ns, line_div=ld)
                 for i, (ns, ld) in enumerate([(6.0, 12), (0.0, 20), (12.0, 8), (3.0, 30)])]
-    rng = np.random.RandomState(4)
-    dense = rng.randint(0, 256, (h, w, 3) if c == 3 else (h, w)).astype(np.uint8)          # ink in every row: one band
+    dense = distinct[0][0].copy()
+    dense[:, 40:43] = 25                                                                   # a rule down the page: ink in every row, one band
     blank = np.full((h, w, 3) if c == 3 else (h, w), 231, np.uint8)                        # no ink: a layer of copies
-    distinct += [(dense, []), (blank, [])]
+    distinct += [(dense, distinct[0][1]), (blank, [])]
     bt = mrc.Batch(ctx, n, w, h, c)
     for i in range(n):
         img, hocr = distinct[i % len(distinct)]
