@@ -124,3 +124,30 @@ def test_profile_figures_are_only_attached_to_the_configuration_they_were_taken_
         assert bench._pick_profile('pmc', 'c5', bench.CONFIGS['c5']['inflight']) is None
     finally:
         bench.PROFILE_ROUND = old
+
+
+def test_round4_bench_lines():
+    """The lines of round 4 that survived (profiles/r04_README.md): the full default line and the timed region of the final sources."""
+    with open(os.path.join(ROOT, 'profiles', 'r04_bench_c2.json')) as f:
+        d = json.load(f)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'pipeline_frac'):
+        assert key in d, key
+    assert d['value'] > 9500 and d['unit'] == 'pages/s' and d['vs_baseline'] is None and d['dtype'] == 'u8'
+    r = d['roofline']
+    assert r['kernel'] == 'optimise_rgb' and r['bound'] == 'hbm' and r['traffic'] is None           # no counter pass this round
+    assert abs(r['frac'] - r['achieved'] / 8000.0) < 1e-4 and 0 < r['frac_of_measured_copy'] < 1 and 'isolated' in r
+    assert abs(d['pipeline_frac'] - d['pipeline_alg_GBps'] / 8000.0) < 1e-3
+    s = d['sauvola_roofline']
+    assert s['isolated']['frac'] > 0.2 and 25 < s['valu']['insts_per_px'] < 30
+    assert d['parity']['mismatches'] == 0 and d['parity']['pages_checked'] == 16
+    assert d['config4_stack']['mismatches'] == 0 and d['config4_stack']['all_pages_present']
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['cores'] >= 1
+    assert 'optimise_bands' in d['kernels'] and 'provenance' in d
+    with open(os.path.join(ROOT, 'profiles', 'r04_bench_c2_timed_region_final_sources.json')) as f:
+        t = json.load(f)
+    assert t['value'] > 10000 and t['kernels']['optimise_rgb']['launches'] == 30          # one optimise launch per batch and step
+    with open(os.path.join(ROOT, 'profiles', 'r04_bench_gpus8_on_one_gpu.json')) as f:
+        g = json.loads(f.read().strip().splitlines()[-1])
+    assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
+    assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
