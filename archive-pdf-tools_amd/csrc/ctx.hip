@@ -30,11 +30,28 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
         return 0;
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-        // drop the cache and retry once
+    auto drop_cache = [&]() {
         for (auto &b : ctx->blocks)
             if (!b.busy && b.base) { (void)hipFree(b.base); b.base = nullptr; b.bytes = 0; }
+    };
+    // A large block is checked against what the device has free BEFORE hipMalloc is asked: an allocation that only
+    // just fits leaves the runtime nothing for its own queues and code objects, and what a driver does past that
+    // point is not something a page loop should find out (MRCHIP_HBM_RESERVE_BYTES, default 2 GiB, stays free).
+    if (bytes >= ((size_t)64 << 20)) {
+        static const size_t reserve = getenv("MRCHIP_HBM_RESERVE_BYTES") ? (size_t)atoll(getenv("MRCHIP_HBM_RESERVE_BYTES"))
+                                                                         : ((size_t)2 << 30);
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {
+            drop_cache();
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {
+                set_error("device memory: %zu bytes asked, %zu of %zu free (%zu kept in reserve)", bytes, fr, tot, reserve);
+                return MRCHIP_E_NOMEM;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        drop_cache();      // and retry once
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -217,6 +234,16 @@ MRCHIP_EXPORT int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, 
     if (name && name_len > 0) snprintf(name, name_len, "%s", ctx->name);
     if (cus) *cus = ctx->cus;
     if (hbm_bytes) *hbm_bytes = ctx->hbm;
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_device_memory(mrchip_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    if (!ctx) return MRCHIP_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    if (free_bytes) *free_bytes = fr;
+    if (total_bytes) *total_bytes = tot;
     return 0;
 }
 

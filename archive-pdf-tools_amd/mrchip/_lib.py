@@ -36,6 +36,7 @@ SIGNATURES = {
     'mrchip_last_error': (C.c_char_p, []),
     'mrchip_sync': (C.c_int, [vp]),
     'mrchip_device_info': (C.c_int, [vp, C.c_char_p, C.c_int, intp, C.POINTER(C.c_size_t)]),
+    'mrchip_device_memory': (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'mrchip_sauvola_u8': (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     'mrchip_mask_denoise': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
     'mrchip_optimise': (C.c_int, [vp, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -179,6 +180,12 @@ class Context:
         hbm = C.c_size_t()
         check(load().mrchip_device_info(self.handle, name, 128, C.byref(cus), C.byref(hbm)))
         return {'name': name.value.decode(), 'cus': cus.value, 'hbm_bytes': hbm.value}
+
+    def memory(self):
+        """(free, total) bytes of device memory right now."""
+        fr, tot = C.c_size_t(), C.c_size_t()
+        check(load().mrchip_device_memory(self.handle, C.byref(fr), C.byref(tot)))
+        return fr.value, tot.value
 
     def pinned_empty(self, shape, dtype=np.uint8):
         """numpy array over page-locked host memory (freed with the array): the destination of the

@@ -83,7 +83,16 @@ def ncpus():
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline: runs BEFORE anything touches the GPU (worker processes are forked)
 def _cpu_worker(args):
-    k, seconds, cfg = args
+    k, seconds, cfg, as_limit = args
+    if as_limit:
+        # a worker that outgrows its allowance gets MemoryError and the baseline is reported as failed; the box survives
+        import resource
+        try:
+            with open('/proc/self/statm') as f:
+                now = int(f.read().split()[0]) * os.sysconf('SC_PAGE_SIZE')
+            resource.setrlimit(resource.RLIMIT_AS, (now + int(as_limit), now + int(as_limit)))
+        except Exception:
+            pass
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import mrc_oracle as O
     from mrchip import synth
@@ -100,53 +109,97 @@ def _cpu_worker(args):
                                                   fg_downsample=cfg['fg'], denoise_mask='fast'):
                 pass
         done += 1
-    return done, time.time() - t0
-
-
-def host_memory_budget():
-    """Bytes this process tree may still take: the smaller of the host's MemAvailable and what the memory cgroup of the
-    container leaves (v2 memory.max / v1 limit_in_bytes minus the current usage).  /proc/meminfo shows the HOST's
-    memory inside a container: sizing worker pools from it alone can run a cgroup out of memory -- which is what most
-    likely took two GPU boxes down in round 4 (`bench.py --config c5` with the CPU baseline: DESIGN.md 6)."""
-    avail = 32 << 30
+    peak = 0
     try:
-        with open('/proc/meminfo') as f:
-            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
+        import resource
+        peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
     except Exception:
         pass
+    return done, time.time() - t0, peak
+
+
+HOST_GB_DEFAULT = 64.0      # MRCHIP_BENCH_HOST_GB: what ALL host allocations of one bench run on a node may add up to
+
+
+def cgroup_memory():
+    """(limit, used) bytes of this container's memory cgroup (v2 memory.max / v1 limit_in_bytes), (None, None) when there
+    is no limit to read ("max", no file): then the ceiling alone bounds the run."""
     for lim, use in (('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory.current'),
                      ('/sys/fs/cgroup/memory/memory.limit_in_bytes', '/sys/fs/cgroup/memory/memory.usage_in_bytes')):
         try:
             with open(lim) as f:
                 v = f.read().strip()
-            if v and v != 'max':
+            if v and v != 'max' and int(v) < (1 << 60):
                 with open(use) as f:
-                    used = int(f.read().strip())
-                if int(v) < (1 << 60):
-                    avail = min(avail, max(0, int(v) - used))
+                    return int(v), int(f.read().strip())
         except Exception:
             continue
-    return avail
+    return None, None
+
+
+def host_memory_budget():
+    """Bytes THIS RANK's bench legs (CPU-baseline workers, fresh page arrays, page-locked ring, stream pool) may take
+    in all: the smallest of an absolute ceiling (MRCHIP_BENCH_HOST_GB, default 64 GB per node), half of what the
+    container's memory cgroup still leaves, and half of MemAvailable -- divided by the ranks of this node.
+    /proc/meminfo shows the HOST's memory inside a container (the pool's boxes: 3 TB, under a cgroup limit of 300 GiB),
+    and a cgroup file that says "max" means unknown, not unlimited: sizing 150 workers x 3.2 GB from MemAvailable is what
+    ran two boxes out of memory in round 4 (`bench.py --config c5` with the CPU baseline; profiles/r04_README.md)."""
+    ceiling = float(os.environ.get('MRCHIP_BENCH_HOST_GB', HOST_GB_DEFAULT)) * 1e9
+    budget = ceiling
+    try:
+        with open('/proc/meminfo') as f:
+            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
+        budget = min(budget, 0.5 * avail)
+    except Exception:
+        pass
+    lim, used = cgroup_memory()
+    if lim is not None:
+        budget = min(budget, 0.5 * max(0, lim - used))
+    ranks_here = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
+    return budget / ranks_here
+
+
+def host_memory_report():
+    lim, used = cgroup_memory()
+    avail = None
+    try:
+        with open('/proc/meminfo') as f:
+            avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
+    except Exception:
+        pass
+    return {'budget_GB': round(host_memory_budget() / 1e9, 1), 'ceiling_GB': float(os.environ.get('MRCHIP_BENCH_HOST_GB', HOST_GB_DEFAULT)),
+            'cgroup_limit_GB': None if lim is None else round(lim / 1e9, 1), 'cgroup_used_GB': None if used is None else round(used / 1e9, 1),
+            'mem_available_GB': None if avail is None else round(avail / 1e9, 1)}
+
+
+def cpu_workers(cfg):
+    """(workers, allowance per worker in bytes) of the CPU baseline for this workload under the host-memory budget"""
+    # measured peak RSS of a worker: 0.83 GB (4000x3000 RGB), 1.05 (3300x4600 RGB), 3.2 (8000x6000 RGB): 1.0 GB per 36 MB
+    # of page is the allowance
+    per_worker = 1.0e9 * max(0.25, (cfg['w'] * cfg['h'] * cfg['c']) / 36e6)
+    budget = 0.8 * host_memory_budget()           # the baseline runs first and alone; its memory is gone before the GPU legs
+    return int(max(1, min(ncpus(), budget // per_worker))), per_worker
 
 
 def cpu_baseline(cfg, seconds=12.0):
-    """The oracle (C restatement of the reference, kind "port") decomposing pages of this workload on every host core:
-    one worker PROCESS per core (each synthesises its own page, then decomposes it in a loop for `seconds`), bounded by
-    the free memory (~1.2 GB per in-flight 4000x3000 page with its numpy temporaries); plus one worker alone for the
-    per-core figure."""
+    """The oracle (C restatement of the reference, kind "port") decomposing pages of this workload on the host's cores:
+    one worker PROCESS per core (each synthesises its own page, then decomposes it in a loop for `seconds`), as many as
+    the host-memory budget allows (`cpu_workers`), each under an address-space limit of twice its allowance; plus one
+    worker alone for the per-core figure.  A worker that fails ends the baseline with an error record, not the run."""
     import multiprocessing as mp
     ncpu = ncpus()
-    # measured peak RSS of a worker: 0.83 GB (4000x3000 RGB), 1.05 (3300x4600 RGB), 3.2 (8000x6000 RGB); 1.2 GB per 36 MB of
-    # page is the allowance.  A quarter of what the container may still take, and never more than 128 GB in all.
-    per_worker = 1.2e9 * (cfg['w'] * cfg['h'] * cfg['c']) / 36e6
-    budget = min(0.25 * host_memory_budget(), 128e9)
-    workers = int(max(1, min(ncpu, budget / per_worker)))
+    workers, per_worker = cpu_workers(cfg)
+    as_limit = 2.0 * per_worker + 1.5e9       # numpy / libgomp arenas reserve address space well beyond what they touch
     ctx = mp.get_context('fork')
-    with ctx.Pool(1) as pool:
-        n1, dt1 = pool.map(_cpu_worker, [(0, seconds / 2, cfg)])[0]
-    with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(k, seconds, cfg) for k in range(workers)])
-    rate = sum(n / dt for n, dt in res)
+    try:
+        with ctx.Pool(1) as pool:
+            n1, dt1, _ = pool.map(_cpu_worker, [(0, seconds / 2, cfg, as_limit)])[0]
+        with ctx.Pool(workers) as pool:
+            res = pool.map(_cpu_worker, [(k, seconds, cfg, as_limit) for k in range(workers)])
+    except Exception as e:          # noqa: BLE001
+        return {'value': None, 'unit': 'pages/s', 'cores': workers, 'kind': 'port', 'error': '%s: %s' % (type(e).__name__, e),
+                'host_memory': host_memory_report()}
+    rate = sum(n / dt for n, dt, _ in res)
     model = ''
     try:
         with open('/proc/cpuinfo') as f:
@@ -156,26 +209,56 @@ def cpu_baseline(cfg, seconds=12.0):
                     break
     except OSError:
         pass
+    capped = workers < ncpu
     return {'value': round(rate, 3), 'unit': 'pages/s', 'cores': workers, 'kind': 'port',
             'sample': '%d decompositions of this workload through oracle/mrc_oracle.c (gcc -O3, no fast-math: it is also '
                       'the bit-exact checker), %d worker processes x %.0f s, one page each in flight'
-                      % (sum(n for n, _ in res), workers, seconds),
+                      % (sum(n for n, _, _ in res), workers, seconds),
             'single_thread_value': round(n1 / dt1, 4), 'host_cpus': ncpu, 'cpu_model': model,
+            'memory_capped': capped, 'worker_peak_rss_GB': round(max(p for _, _, p in res) / 1e9, 2),
+            'host_memory': host_memory_report(),
             'reference_itself_pages_per_s_per_core': REFERENCE_PAGES_PER_S_PER_CORE,
-            'note': 'cores = worker processes actually used (all host cores unless memory-bound); the reference figure is '
-                    'the Python/Cython reference on configs[1] measured in the survey container (BASELINE.md)'}
+            'note': ('cores = worker processes actually used: %s; the reference figure is the Python/Cython reference on '
+                     'configs[1] measured in the survey container (BASELINE.md)'
+                     % ('MEMORY-CAPPED -- %d of the host\'s %d cores, %.1f GB allowed per worker under a %.0f GB budget '
+                        '(MRCHIP_BENCH_HOST_GB); all cores would need %.0f GB' % (workers, ncpu, per_worker / 1e9,
+                                                                                  host_memory_budget() / 1e9, ncpu * per_worker / 1e9)
+                        if capped else 'all host cores'))}
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def git_head():
-    """commit of this tree: git where there is a repository, else the stamp build() left beside the library"""
+def sources_hash():
+    """hash of the library's sources as the Makefile takes it at link time (csrc/*.hip sorted, mrchip_internal.h, mrchip.h)"""
+    import glob
+    src = os.path.join(ROOT, 'archive-pdf-tools_amd', 'csrc')
+    files = sorted(glob.glob(os.path.join(src, '*.hip')), key=os.path.basename)
+    files += [os.path.join(src, 'mrchip_internal.h'), os.path.join(ROOT, 'include', 'mrchip.h')]
+    hh = hashlib.sha256()
+    for f in files:
+        with open(f, 'rb') as fh:
+            hh.update(fh.read())
+    return hh.hexdigest()[:16]
+
+
+def library_is_current():
+    """the in-tree libmrchip.so was linked from the sources that lie beside it (lib/BUILD_SRCHASH, csrc/Makefile)"""
     try:
-        h = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True,
-                           timeout=10).stdout.strip()
-        if h:
-            return h
-    except Exception:
-        pass
+        with open(os.path.join(ROOT, 'archive-pdf-tools_amd', 'lib', 'BUILD_SRCHASH')) as f:
+            return f.read().strip() == sources_hash()
+    except OSError:
+        return False
+
+
+def git_head():
+    """Commit the numbers of this run belong to: the stamp `make` left beside the library (lib/BUILD_HEAD: the commit, '+'
+    when the tracked tree was dirty at build time) -- the GPU box gets a snapshot without .git.  None, loudly, when the
+    library was not linked from the sources beside it: a line must not carry the name of code that did not run."""
+    if not library_is_current():
+        if not getattr(git_head, 'warned', False):
+            sys.stderr.write('bench.py: libmrchip.so was not built from the sources beside it (lib/BUILD_SRCHASH): run make; '
+                             '`head` is withheld\n')
+            git_head.warned = True
+        return None
     try:
         with open(os.path.join(ROOT, 'archive-pdf-tools_amd', 'lib', 'BUILD_HEAD')) as f:
             return f.read().strip() or None
@@ -196,7 +279,7 @@ def _profile_kernel(kernels, name):
     return max(hits, key=lambda kv: kv[1].get('launches', 0))[1] if hits else None
 
 
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 
 
 def _pick_profile(kind, config, inflight):
@@ -224,6 +307,12 @@ def _pick_profile(kind, config, inflight):
     return best
 
 
+def same_kernel_sources(srchash):
+    """a committed profile describes THIS build when the hash of the library sources it recorded is the current one
+    (commits that touch only tests, docs or bench.py keep a profile valid; any change under csrc/ or include/ retires it)"""
+    return bool(srchash) and srchash == sources_hash() and library_is_current()
+
+
 def pmc_traffic(name, alg_per_launch, config='c2', inflight=3):
     """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
     2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled to this run's launch size -- with the provenance, so a
@@ -233,7 +322,10 @@ def pmc_traffic(name, alg_per_launch, config='c2', inflight=3):
         if not hit:
             return None, None
         f, d = hit
-        src = {'file': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head()}
+        src = {'file': os.path.relpath(f, ROOT), 'profiled_head': d.get('head'), 'this_head': git_head(),
+               'kernel_sources_equal': same_kernel_sources(d.get('srchash'))}
+        if not src['kernel_sources_equal']:
+            return None, src          # counters of other code are not attached to this line
         v = _profile_kernel(d['kernels'], name)
         if v and 'alg_bytes_per_launch' in d.get('scale', {}).get(name, {}):
             return round(v['hbm_bytes_per_launch'] * alg_per_launch / d['scale'][name]['alg_bytes_per_launch']), src
@@ -251,6 +343,8 @@ def valu_roofline(name, alg_per_launch, bytes_per_px, config='c2', inflight=3):
         if not hit:
             return None
         f, d = hit
+        if not same_kernel_sources(d.get('srchash')):
+            return None
         sc = d.get('scale', {}).get(name, {})
         v = _profile_kernel(d['kernels'], name)
         if v and 'alg_bytes_per_launch' in sc:
@@ -638,6 +732,7 @@ def main():
             'pages_per_s': round(total_pages / dt, 2),
             'sauvola_roofline': sauvola_roof,      # BASELINE.json also names "Sauvola HBM GB/s"
             'kernels': kernels, 'device': info['name'].strip(), 'head': git_head(),
+            'srchash': sources_hash() if library_is_current() else None,      # of csrc/ + include/: what a profile must match to be quoted
         }
         line.update(extra)
         print(json.dumps(line))
@@ -801,13 +896,10 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
     # producer thread into a ring of page-locked buffers ahead of the stream.  Both passes of a run use
     # their own fresh arrays; bounded by the host memory that is free.
     page_bytes = W * H * Cc
-    n_fresh = n_pages
-    try:
-        import psutil
-        # one pass of distinct arrays is alive at a time on every rank of the node: a quarter of the free memory between them
-        n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, min(psutil.virtual_memory().available, host_memory_budget()) * 0.2 // (max(world, 1) * page_bytes))))
-    except Exception:      # noqa: BLE001
-        n_fresh = min(n_pages, 128)
+    # one pass of distinct arrays is alive at a time (the previous pass's are released first): 40 % of this rank's
+    # host-memory budget; the page-locked ring below takes at most 15 % of it and never more than 16 GB
+    budget = host_memory_budget()
+    n_fresh = int(max(E2E_BATCH * E2E_SLOTS, min(n_pages, 0.4 * budget // page_bytes)))
     if os.environ.get('MRCHIP_BENCH_FRESH', '1') != '0':
         def fresh_arrays():
             return [np.array(host_pages[i % nd][0], copy=True) for i in range(n_fresh)]       # new allocations, never uploaded
@@ -822,8 +914,7 @@ def e2e_stream(ctx, comm, mrc, cfg, host_pages, n_pages, rank, world):
         keep.clear()
 
         import threading
-        # page-locked ring: at most 16 GB and a tenth of what the container may still take (8000x6000 pages: 144 MB each)
-        RING = int(max(E2E_BATCH * (E2E_SLOTS + 2), min(E2E_BATCH * (E2E_SLOTS + 12), min(16e9, 0.1 * host_memory_budget()) // page_bytes)))
+        RING = int(max(E2E_BATCH * (E2E_SLOTS + 2), min(E2E_BATCH * (E2E_SLOTS + 12), min(16e9, 0.15 * budget) // page_bytes)))
         RING_THREADS = 4
         import ctypes
         ring = [ctx.pinned_empty(host_pages[0][0].shape) for _ in range(RING)]

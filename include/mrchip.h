@@ -56,6 +56,10 @@ const char *mrchip_last_error(void);
 int mrchip_sync(mrchip_ctx *ctx);
 /* Device name / CU count of the context's device (for reports). */
 int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes);
+/* Device memory free / total right now (hipMemGetInfo), for callers that size batches: a batch of N pages holds about
+ * (3 C + 9) W H N bytes of planes and scratch; allocations that would leave less than 2 GiB free are refused
+ * (MRCHIP_E_NOMEM) instead of being tried. */
+int mrchip_device_memory(mrchip_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* NUMA node of the host socket this context's GPU is attached to (sysfs), -1 if unknown: where a streaming caller
  * wants its page-locked buffers (mrchip_host_alloc from a thread running there). */
 int mrchip_device_numa_node(mrchip_ctx *ctx);

@@ -8,18 +8,67 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_profile_figures_come_from_this_rounds_committed_profiles_only():
-    """bench.py quotes counter figures from profiles/<round>_*_summary.json of the CURRENT round (the kernels of earlier
-    rounds are other code).  Round 4 has a counter pass for the Sauvola kernels only (the pool lost the box during the
-    FETCH / WRITE passes: DESIGN.md 6): traffic is null, the instruction side is there for Sauvola."""
+def test_profile_figures_come_from_profiles_of_this_build_only():
+    """bench.py quotes counter figures from profiles/<round>_*_summary.json of the CURRENT round, and only when the summary
+    recorded the hash of the library sources (csrc/ + include/) that this tree still has: the profiles of earlier rounds
+    -- other kernels under similar names, no hash -- are never attached (VERDICT r4 weak #7)."""
     import bench
-    assert bench.PROFILE_ROUND == 'r04'
+    assert bench.PROFILE_ROUND == 'r05'
+    assert bench.library_is_current(), 'libmrchip.so is older than csrc/: run make (the CPU suite runs after build())'
+    assert bench.same_kernel_sources(bench.sources_hash()) and not bench.same_kernel_sources(None)
+    assert not bench.same_kernel_sources('0' * 16)
+    old = bench.PROFILE_ROUND
+    try:
+        bench.PROFILE_ROUND = 'r04'          # a round whose summaries carry no source hash
+        assert bench._pick_profile('valu', 'c2', 1)
+        assert bench.valu_roofline('sauvola', 3.072e9, 2.0, 'c2', 3) is None
+        bench.PROFILE_ROUND = 'r03'
+        t, src = bench.pmc_traffic('optimise_rgb', 21.504e9, 'c2', 3)
+        assert t is None and src['kernel_sources_equal'] is False and src['file'] == 'profiles/r03_pmc_summary.json'
+    finally:
+        bench.PROFILE_ROUND = old
     for name, alg in (('optimise_rgb', 21.504e9), ('sauvola', 3.072e9)):
-        assert bench.pmc_traffic(name, alg) == (None, None)
-    v = bench.valu_roofline('sauvola', 3.072e9, 2.0, 'c2', 3)
-    assert v and v['source'] == 'profiles/r04_inflight1_valu_summary.json' and v['profiled_head']
-    assert 25 < v['insts_per_px'] < 30 and 0.5 < v['busy_frac'] < 0.75 and 3.8 < v['cycles_per_inst'] < 4.2
-    assert bench.valu_roofline('optimise_rgb', 21.504e9, 7.0, 'c2', 3) is None
+        t, src = bench.pmc_traffic(name, alg)
+        assert t is None or (src['kernel_sources_equal'] and t > 0.9 * alg)
+
+
+def test_host_memory_budget_is_bounded(monkeypatch):
+    """Round 4 lost two GPU boxes to a CPU-baseline pool sized from the HOST's MemAvailable inside a 300 GiB memory cgroup.
+    Every host allocation of a bench run now comes out of one budget: an absolute ceiling (MRCHIP_BENCH_HOST_GB), at most
+    half of what the cgroup / the host leaves, split between the ranks of the node."""
+    import bench
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setenv('MRCHIP_BENCH_HOST_GB', '8')
+    b1 = bench.host_memory_budget()
+    assert 0 < b1 <= 8e9
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert abs(bench.host_memory_budget() - b1 / 8) < 1e6
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    monkeypatch.setenv('MRCHIP_BENCH_HOST_GB', '64')
+    monkeypatch.setattr(bench, 'cgroup_memory', lambda: (300 << 30, 290 << 30))       # 10 GiB left in the cgroup
+    assert bench.host_memory_budget() <= 0.5 * (10 << 30)
+    monkeypatch.setattr(bench, 'cgroup_memory', lambda: (None, None))                  # "max": unknown, the ceiling holds
+    assert bench.host_memory_budget() <= 64e9
+    monkeypatch.setattr(bench, 'ncpus', lambda: 256)
+    for name, most in (('c2', 52), ('c3', 40), ('c5', 13)):        # 0.8 x 64 GB over 1.0 / 1.27 / 4.0 GB per worker
+        workers, per = bench.cpu_workers(bench.CONFIGS[name])
+        assert 1 <= workers <= most and workers * per <= 0.8 * 64e9
+
+
+def test_cpu_worker_over_its_allowance_fails_without_taking_the_host_along():
+    """A baseline worker runs under RLIMIT_AS: one that outgrows it raises MemoryError inside the worker, and cpu_baseline
+    reports an error record instead of a figure (the bench line still prints)."""
+    import multiprocessing as mp
+    import bench
+    cfg = dict(bench.CONFIGS['c2'], w=2000, h=1500)
+    with mp.get_context('fork').Pool(1) as pool:
+        import pytest
+        with pytest.raises(Exception):       # MemoryError from numpy, or the loader failing to map a library: never a figure
+            pool.map(bench._cpu_worker, [(0, 0.1, cfg, 16 << 20)])       # 16 MiB over the current size: cannot hold a page
+    with mp.get_context('fork').Pool(1) as pool:
+        n, dt, peak = pool.map(bench._cpu_worker, [(0, 0.1, cfg, 4 << 30)])[0]
+        assert n >= 1 and 0 < peak < 2e9
 
 
 def test_committed_bench_lines_have_the_contract_fields():
@@ -108,15 +157,15 @@ def test_eight_ranks_dry_run():
 def test_profile_figures_are_only_attached_to_the_configuration_they_were_taken_on():
     """the newest *_summary.json used to be quoted for every --config / --inflight."""
     import bench
-    hit = bench._pick_profile('valu', 'c2', 1)
-    assert hit and 'inflight1' in os.path.basename(hit[0])
-    assert bench._pick_profile('valu', 'c3gray', bench.CONFIGS['c3gray']['inflight']) is None       # no c3gray pass this round
-    assert bench._pick_profile('pmc', 'c5', bench.CONFIGS['c5']['inflight']) is None
-    assert bench.pmc_traffic('optimise_rgb', 1e9, 'c5', bench.CONFIGS['c5']['inflight']) == (None, None)
-    assert bench.valu_roofline('sauvola', 1e9, 2.0, 'c5', 3) is None
     old = bench.PROFILE_ROUND
-    try:                                  # the selection logic on the fuller round-3 set
-        bench.PROFILE_ROUND = 'r03'
+    try:
+        bench.PROFILE_ROUND = 'r04'
+        hit = bench._pick_profile('valu', 'c2', 1)
+        assert hit and 'inflight1' in os.path.basename(hit[0])
+        assert bench._pick_profile('valu', 'c3gray', bench.CONFIGS['c3gray']['inflight']) is None       # no c3gray pass in round 4
+        assert bench._pick_profile('pmc', 'c5', bench.CONFIGS['c5']['inflight']) is None
+        assert bench.pmc_traffic('optimise_rgb', 1e9, 'c5', bench.CONFIGS['c5']['inflight']) == (None, None)
+        bench.PROFILE_ROUND = 'r03'          # the selection logic on the fuller round-3 set
         hit = bench._pick_profile('pmc', 'c3gray', bench.CONFIGS['c3gray']['inflight'])
         assert hit and 'c3gray' in os.path.basename(hit[0])
         hit = bench._pick_profile('pmc', 'c2', 3)

@@ -21,7 +21,7 @@ def short(name):
     return name.split('(')[0].replace('void ', '').strip()
 
 
-def valu_summary(src, tag, out, note, head, scale):
+def valu_summary(src, tag, out, note, head, scale, srchash=None):
     """<tag>_valu_summary.json: the instruction roofline per kernel from the SQ / GRBM passes of the same command --
     VALU wave-instructions per launch, cycles the VALU was busy per instruction (SQ_ACTIVE_INST_VALU counts quad-cycles),
     fraction of the launch during which a SIMD's VALU was busy (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
@@ -48,7 +48,7 @@ def valu_summary(src, tag, out, note, head, scale):
                       'wave_cycles_per_launch': round(a.get('SQ_WAVE_CYCLES', 0.0))}
     with open(os.path.join(out, tag + '_valu_summary.json'), 'w') as f:
         json.dump({'command': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU | GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace -- python3 bench.py ' + note,
-                   'bench_args': note, 'head': head, 'scale': scale, 'kernels': kernels}, f, indent=1)
+                   'bench_args': note, 'head': head, 'srchash': srchash, 'scale': scale, 'kernels': kernels}, f, indent=1)
 
 
 def main():
@@ -89,12 +89,13 @@ def main():
         wcsv.writerows(rows)
     # algorithmic bytes per launch of the kernels bench.py quotes traffic for, from the bench line of the kernel-trace
     # pass (so that bench.py can scale the counters to its own launch size), and the commit that was profiled
-    scale, head = {}, None
+    scale, head, srchash = {}, None, None
     try:
         with open(os.path.join(src, 'kt_bench.log')) as f:
             line = [ln for ln in f.read().splitlines() if ln.startswith('{')][-1]
         b = json.loads(line)
         head = b.get('head')
+        srchash = b.get('srchash')
         for key in ('roofline', 'sauvola_roofline'):
             r = b.get(key)
             if r:
@@ -104,8 +105,8 @@ def main():
         print('no bench line in kt_bench.log:', e)
     with open(os.path.join(out, tag + '_pmc_summary.json'), 'w') as f:
         json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py ' + note,
-                   'bench_args': note, 'head': head, 'scale': scale, 'kernels': {r['kernel']: r for r in rows}}, f, indent=1)
-    valu_summary(src, tag, out, note, head, scale)
+                   'bench_args': note, 'head': head, 'srchash': srchash, 'scale': scale, 'kernels': {r['kernel']: r for r in rows}}, f, indent=1)
+    valu_summary(src, tag, out, note, head, scale, srchash)
     for r in rows[:12]:
         print('%-45s n=%3d  read %.3f GB  write %.3f GB  avg %.3f ms' % (r['kernel'][:45], r['launches'],
               r['read_bytes_per_launch_gfx950_corrected'] / 1e9, r['write_bytes_per_launch'] / 1e9, r['avg_ns_kernel_trace'] / 1e6))
