@@ -1374,7 +1374,10 @@ __global__ __launch_bounds__(MAXT) void optimise_band_kernel(const OptJob *jobs,
         // rows outside the band are copies either way, and without the band's bounds that loop is ~30 % leaner in
         // scalar instructions (measured: fg layers 5.2 -> 4.9 ms per 128 pages).
         const StripInfo NOSTRIP = StripInfo{1, 0, nullptr, 0, nullptr};
-        const OptBand *bp = (B.y1 - B.y0) * 10 >= J.h * 9 ? nullptr : &B;
+        // Only when the band is the job's ONLY band (it owns every row: c0 = 0, c1 = h): the whole-page instance
+        // computes and stores all h rows, and another band of the same job walked at the same time by another workgroup
+        // would have its rows written twice with no ordering (identical bytes, but not a pattern to rely on).
+        const OptBand *bp = ((B.y1 - B.y0) * 10 >= J.h * 9 && B.c0 == 0 && B.c1 == J.h) ? nullptr : &B;
         if (bp) {
             if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
             else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
@@ -1518,12 +1521,13 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
     }
     int n_min = n_max;
     for (int i = 0; i < njobs; i++) n_min = std::min(n_min, h_jobs[i].n);
-    OptGeom g;
-    TRY(opt_geometry(w, c, n_max, &g));
-    // Whole rows of <= 4096 columns on one workgroup, n <= 11: the band walkers (optimise_band_kernel).  They read the
-    // mask at 1 bit per pixel: callers that only have bytes get a packed copy.
+    if (n_max < 0 || n_max > 32) { set_error("optimise: n_size %d outside [0,32]", n_max); return MRCHIP_E_UNSUPPORTED; }
+    // Whole rows of <= 4096 columns on one workgroup (four columns per thread), n <= 11: the band walkers
+    // (optimise_band_kernel).  They read the mask at 1 bit per pixel: callers that only have bytes get a packed copy.
+    // The whole-row geometry (opt_geometry: it refuses rows that do not fit one workgroup's LDS) is only asked for once
+    // the column strips have declined the launch: rows of more than 4096 columns always go in strips, whatever their width.
     static const bool no_bands = getenv("MRCHIP_OPT_BANDS") && atoi(getenv("MRCHIP_OPT_BANDS")) == 0;
-    const bool bands = !no_bands && g.P == 4 && n_max <= 11 && n_min >= 1 && h < 65536;
+    const bool bands = !no_bands && cdiv(w, 4) <= 1024 && n_max <= 11 && n_min >= 1 && h < 65536;
     if (bands) {
         const int wpr = cdiv(w, 32);
         const size_t per = (size_t)wpr * h * sizeof(unsigned);
@@ -1564,6 +1568,8 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
         if (st != 0) return st < 0 ? st : 0;
     }
+    OptGeom g;
+    TRY(opt_geometry(w, c, n_max, &g));
     const double alg = (1.0 + 2.0 * c) * w * h * njobs;
 #define OPT_LAUNCH(CC, PP, MT, NAME)                                                                     \
     do {                                                                                                \

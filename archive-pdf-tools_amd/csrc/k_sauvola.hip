@@ -740,7 +740,8 @@ static const SauvolaCounts *count_tables(mrchip_ctx *ctx, int ww, int wh) {
 }
 
 // The decision table of one (k, R): built on the device on first use (bisection with the general path's predicate),
-// compacted on the host to the band of d = px - mean whose entries are not constant, kept for the life of the process.
+// compacted on the host to the band of d = px - mean whose entries are not constant, kept for the life of the process
+// (a bounded number of them).
 struct SauvolaTable {
     int dev; double k, R;
     unsigned short *d_tab = nullptr;
@@ -753,6 +754,12 @@ static const SauvolaTable *decision_table(mrchip_ctx *ctx, double k, double R) {
     std::lock_guard<std::mutex> lock(mu);
     for (auto *e : cache)
         if (e->dev == ctx->device && e->k == k && e->R == R) return e;
+    // The cache is bounded: at most MAX_TABLES tables per process (<= 130 KB of device memory each); a caller that
+    // keeps inventing (k, R) pairs beyond that gets the general fp64 path for the new ones -- exact, slower -- instead of
+    // an unbounded leak.  Entries are never freed (launches in flight read them without a lock).
+    constexpr size_t MAX_TABLES = 64;
+    static const SauvolaTable none = {};
+    if (cache.size() >= MAX_TABLES) return &none;
     auto *e = new SauvolaTable;
     e->dev = ctx->device; e->k = k; e->R = R;
     cache.push_back(e);                      // a failed build is remembered too (ok = false: the general path)
@@ -811,7 +818,7 @@ int sauvola_table_selftest(mrchip_ctx *ctx, hipStream_t s, double k, double R, u
     return 0;
 }
 
-// one-time opt-in of a kernel to more dynamic LDS than the default limit
+// opt-in of a kernel (on the current device) to more dynamic LDS than the default limit
 template <class F>
 static int allow_dynamic_lds(F *kernel, int bytes) {
     HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -867,13 +874,14 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
         constexpr int NW = K == 8 ? 16 : 8, WPE = K == 8 ? 4 : 6;
         const int dyn = P.tab_bytes + 16 * P.colrec_n;
         const int stat = NW * K * (64 + 2 * (small_pl ? 8 : 32)) * 8;
-        if (P.tab && (K == 4 || small_pl) && stat + dyn <= 160 * 1024) {
+        // (K = 8 with two polarities never gets here with a table: sauvola_columns_per_lane keeps box launches of table-sized
+        // windows on 4 columns, and wider windows have no small_pl)
+        if (P.tab && (K == 4 || (small_pl && !both)) && stat + dyn <= 160 * 1024) {
             dim3 grid(cdiv(P.strips * P.ytiles, NW), 1, njobs);
 #define SAUVOLA_TAB_LAUNCH(MULTI_, BOTH_, PL_)                                                                         \
     do {                                                                                                               \
         auto *kern = sauvola_tab_kernel<K, MULTI_, BOTH_, PL_, NW, WPE>;                                               \
-        static int allowed = 0;                                                                                        \
-        if (allowed < dyn) { TRY(allow_dynamic_lds(kern, dyn)); allowed = dyn; }                                       \
+        TRY(allow_dynamic_lds(kern, dyn));        /* per device, cheap: set on every launch (several GPUs per process) */ \
         LAUNCH(ctx, s, nm, alg_bytes, hipLaunchKernelGGL(kern, grid, dim3(64 * NW), dyn, s, h_jobs[0], d_jobs, P));    \
     } while (0)
 #define SAUVOLA_TAB_LAUNCH_PL(MULTI_, BOTH_)                                                                           \
@@ -883,9 +891,9 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     } while (0)
             switch (sel) {
                 case 0: SAUVOLA_TAB_LAUNCH_PL(false, false); break;
-                case 1: SAUVOLA_TAB_LAUNCH_PL(false, true); break;
                 case 2: SAUVOLA_TAB_LAUNCH_PL(true, false); break;
-                default: SAUVOLA_TAB_LAUNCH_PL(true, true); break;
+                case 1: if constexpr (K == 4) SAUVOLA_TAB_LAUNCH_PL(false, true); break;
+                default: if constexpr (K == 4) SAUVOLA_TAB_LAUNCH_PL(true, true); break;
             }
 #undef SAUVOLA_TAB_LAUNCH_PL
 #undef SAUVOLA_TAB_LAUNCH
@@ -941,10 +949,13 @@ int sauvola_div_selftest(mrchip_ctx *ctx, hipStream_t s, unsigned long long *d_b
 }
 
 // columns per lane of the kernel a launch takes
-static int sauvola_columns_per_lane(int maxw, int maxh, int ww) {
+static int sauvola_columns_per_lane(int maxw, int maxh, int ww, bool both) {
     // 8 columns per lane halve the strip halo (452 of 512 columns are outputs instead of 200 of 256) at the
-    // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops
-    const bool page_like = maxw >= 1024 && maxh >= 256;
+    // price of 128 VGPRs: measured 12 % faster on whole pages, 10 % slower on the short hOCR-box crops.  A two-polarity
+    // launch (hOCR boxes) stays on 4 columns whatever the size of its boxes: with the second polarity's table entries
+    // and form bits live across the compare loop the 8-column table kernel does not fit 128 VGPRs (8 spilled, and it
+    // measured 1.9x slower on boxes), so that instantiation does not exist.
+    const bool page_like = maxw >= 1024 && maxh >= 256 && !both;
     if (ww <= 120 && !page_like) return 4;
     return ww <= 360 ? 8 : 16;
 }
@@ -995,13 +1006,15 @@ int launch_sauvola_dev(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, c
             return MRCHIP_E_ARG;
         }
     }
-    const int K = sauvola_columns_per_lane(maxw, maxh, ww);
+    bool both = false;
+    for (int i = 0; i < njobs; i++) both = both || jobs[i].dst_inv != nullptr;
+    const int K = sauvola_columns_per_lane(maxw, maxh, ww, both);
     if (K == 4) return launch_k<4>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     if (K == 8) return launch_k<8>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
     return launch_k<16>(ctx, s, jobs, d_jobs, njobs, P, maxw, maxh, alg);
 }
 
-bool sauvola_writes_bits(int maxw, int maxh, int ww) { return sauvola_columns_per_lane(maxw, maxh, ww) >= 8; }
+bool sauvola_writes_bits(int maxw, int maxh, int ww) { return sauvola_columns_per_lane(maxw, maxh, ww, false) >= 8; }
 
 int launch_sauvola(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *jobs, int njobs,
                    int ww, int wh, double k, double R, int flags) {

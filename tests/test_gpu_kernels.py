@@ -258,6 +258,22 @@ def test_optimise_whole_rows_and_column_strips_agree_with_the_oracle(monkeypatch
             assert np.array_equal(got, exp), ((h, w, c, n, dens), mode, int((got != exp).sum()))
 
 
+@pytest.mark.parametrize('h,w,c,n', [(40, 10007, 3, 3), (37, 10007, 3, 10), (30, 17001, 1, 10), (24, 9217, 3, 11), (20, 16385, 1, 3),
+                                     (16, 20011, 3, 10)])
+def test_optimise_large_format_rows_take_column_strips_whatever_their_width(h, w, c, n):
+    """rows of more than 4096 columns always go in column strips of <= 1024 threads, so their width is
+    not bounded by one workgroup's LDS (RGB > 9216, gray > 16384 were refused when the whole-row geometry was asked first)."""
+    import mrc_oracle as O
+    from mrchip import optimiser
+    rng = np.random.RandomState(w + n)
+    img = rng.randint(0, 256, (h, w, c) if c == 3 else (h, w)).astype(np.uint8)
+    mask = (rng.rand(h, w) < 0.15).astype(np.uint8)
+    mask[:, w - 40:] = 0                    # unselected pixels at the right edge of the last strip
+    exp = (O.optimise_gray2 if c == 1 else O.optimise_rgb2)(mask, img, w, h, n)
+    got = (optimiser.optimise_gray2 if c == 1 else optimiser.optimise_rgb2)(mask, img, w, h, n)
+    assert np.array_equal(got, exp), (h, w, c, n, int((got != exp).sum()))
+
+
 def _band_masks(rng, h, w, n):
     """Masks (1 = selected = copied) whose unselected rows come in runs separated by gaps of chosen lengths."""
     out = []

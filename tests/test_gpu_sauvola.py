@@ -157,6 +157,47 @@ def test_decision_paths_agree_with_the_oracle(mode, monkeypatch):
         assert np.array_equal(m_gpu, m_cpu), (mode, int((m_gpu != m_cpu).sum()))
 
 
+def _headline_page(w, h, seed):
+    """a page whose hOCR has page-like boxes: the whole page, a tall headline, long lines, a light-on-dark banner"""
+    img, _ = synth.synth_page(w, h, 1, seed=seed, noise_sigma=5.0, line_div=18)
+    img[h // 2:h // 2 + 300, 40:w - 60] = 255 - img[h // 2:h // 2 + 300, 40:w - 60]       # inverted-polarity decisions
+    word = [{'text': 'w', 'confidence': 88}]
+    lines = [{'bbox': [0, 0, w, h], 'words': word},                                   # the whole page as one box
+             {'bbox': [30, 20, min(w, 1530), 420], 'words': word},                     # 1500 x 400 headline
+             {'bbox': [10, 440, w - 3, 500], 'words': word},                           # long thin lines beside it
+             {'bbox': [7, 505, w - 11, 566], 'words': word},
+             {'bbox': [40, h // 2, w - 60, h // 2 + 300], 'words': word},              # the light-on-dark banner: 300 rows
+             {'bbox': [w - 1100, h - 290, w, h], 'words': word},                       # touches the right / bottom border
+             {'bbox': [100, 600, 400, 640], 'words': word}]                            # an ordinary small box in the same launch
+    return img, [{'lines': lines}]
+
+
+@pytest.mark.parametrize('mode', ['0', '1'])
+@pytest.mark.parametrize('dpi', [None, 500, 1500])
+def test_page_sized_hocr_boxes_take_the_wide_two_polarity_kernels(mode, dpi, monkeypatch):
+    """a box launch whose boxes reach 1024 columns AND 256 rows switches to 8 columns per lane (16 for
+    windows > 360), i.e. the two-polarity instantiations of the K = 8 / 16 kernels -- table-driven by default, the fp64
+    sequence under MRCHIP_SAUVOLA_FAST=0 or when the window is too wide for the table kernel's strips (dpi 500 -> 125,
+    dpi 1500 -> 375).  create_hocr_mask (mrc.py:222-238: both thresholds, ratios, decisions) and the full page."""
+    from mrchip import mrc
+    monkeypatch.setenv('MRCHIP_SAUVOLA_FAST', mode)
+    for (pw, ph, seed) in [(1700, 1100, 91), (3001, 1203, 92)]:
+        img, hocr = _headline_page(pw, ph, seed)
+        boxes = mrc.hocr_boxes(hocr, pw, ph)
+        assert (boxes[:, 2] - boxes[:, 0]).max() >= 1024 and (boxes[:, 3] - boxes[:, 1]).max() >= 256
+        m_gpu = np.zeros(img.shape, dtype=np.bool_)
+        m_cpu = np.zeros(img.shape, dtype=np.bool_)
+        mrc.create_hocr_mask(img, m_gpu, hocr, dpi=dpi)
+        dec = []
+        O.create_hocr_mask(img, m_cpu, boxes, dpi, dec)
+        assert np.array_equal(m_gpu, m_cpu), (mode, dpi, pw, int((m_gpu != m_cpu).sum()))
+        assert len(set(dec)) > 1, dec          # the boxes do not all decide the same way
+        g = mrc.create_mrc_hocr_components(img, hocr, dpi=dpi, denoise_mask='fast', bg_downsample=3)
+        e = O.create_mrc_hocr_components(img, hocr, dpi=dpi, denoise_mask='fast', bg_downsample=3)
+        for k, (a, b) in enumerate(zip(g, e)):
+            assert a.shape == b.shape and np.array_equal(a, b), (mode, dpi, pw, k)
+
+
 def test_saturated_and_two_level_images():
     """variance 0 / tmp <= 0 boundary and the extreme variances: constant, two-level (0 / 255 halves, stripes, checker),
     saturated borders -- the corners of the decision table."""

@@ -47,3 +47,17 @@ def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
         rc, out = _scan(lst, key)
         assert rc == 0, (key, out[-1500:])
         assert _scratch_of(lst, key) == 0, key
+    # every Sauvola kernel of the library is free of scratch (the 8-column two-polarity table kernel
+    # spilled 8 VGPRs; box launches now stay on 4 columns and that instantiation is gone), and the wide two-polarity
+    # fp64 kernels that page-sized boxes with wide windows DO reach are scanned like the others
+    import re as _re
+    txt = open(lst).read()
+    names = _re.findall(r'\.amdhsa_kernel (\S*sauvola\S*)', txt)
+    assert len(names) > 20
+    assert not [n for n in names if 'sauvola_tab_kernelILi8ELb0ELb1' in n or 'sauvola_tab_kernelILi8ELb1ELb1' in n]
+    for n in names:
+        assert _scratch_of(lst, n) == 0, n
+    for key in ('sauvola_kernelILi8ELb1ELb1ELi32E', 'sauvola_kernelILi8ELb0ELb1ELi32E', 'sauvola_kernelILi16ELb1ELb1ELi32E',
+                'sauvola_kernelILi16ELb0ELb1ELi32E'):
+        rc, out = _scan(lst, key)
+        assert rc == 0, (key, out[-1500:])
