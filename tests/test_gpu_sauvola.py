@@ -173,12 +173,13 @@ def _headline_page(w, h, seed):
 
 
 @pytest.mark.parametrize('mode', ['0', '1'])
-@pytest.mark.parametrize('dpi', [None, 500, 1500])
+@pytest.mark.parametrize('dpi', [None, 500, 1000])
 def test_page_sized_hocr_boxes_take_the_wide_two_polarity_kernels(mode, dpi, monkeypatch):
     """a box launch whose boxes reach 1024 columns AND 256 rows switches to 8 columns per lane (16 for
-    windows > 360), i.e. the two-polarity instantiations of the K = 8 / 16 kernels -- table-driven by default, the fp64
-    sequence under MRCHIP_SAUVOLA_FAST=0 or when the window is too wide for the table kernel's strips (dpi 500 -> 125,
-    dpi 1500 -> 375).  create_hocr_mask (mrc.py:222-238: both thresholds, ratios, decisions) and the full page."""
+    windows > 360) for a PAGE launch; a two-polarity (box) launch stays on 4 columns per lane for table-sized windows
+    (<= 120) and takes the 8-column fp64 kernel beyond (dpi 500 -> window 125, dpi 1000 -> 251; square windows end at
+    256: the 16-column kernel is out of a box launch's reach).  Table-driven by default, the fp64 sequence under
+    MRCHIP_SAUVOLA_FAST=0.  create_hocr_mask (mrc.py:222-238: both thresholds, ratios, decisions) and the full page."""
     from mrchip import mrc
     monkeypatch.setenv('MRCHIP_SAUVOLA_FAST', mode)
     for (pw, ph, seed) in [(1700, 1100, 91), (3001, 1203, 92)]:
