@@ -157,6 +157,30 @@ def test_decision_paths_agree_with_the_oracle(mode, monkeypatch):
         assert np.array_equal(m_gpu, m_cpu), (mode, int((m_gpu != m_cpu).sum()))
 
 
+@pytest.mark.parametrize('counted', ['0', '1'])
+def test_counted_stores_and_plain_stores_agree_with_the_oracle(counted, monkeypatch):
+    """The 8-column page kernel issues its stores as asm under an exec mask -- exactly one vector store (and one byte of the
+    1-bpp row) per row -- so that the hand-counted `s_waitcnt vmcnt(N)` of the row queues can count them; with
+    MRCHIP_SAUVOLA_COUNTED_STORES=0 the compiler's stores run instead.  Widths that are not multiples of 8 (the lane at
+    the right edge stores zeros past column w, into the row's padding), pages through the batch (1-bpp rows fused) and
+    through threshold_image (bytes only), tiles shorter than the queue depth."""
+    from mrchip import mrc
+    monkeypatch.setenv('MRCHIP_SAUVOLA_COUNTED_STORES', counted)
+    rng = np.random.RandomState(17)
+    for (h, w) in [(300, 1027), (257, 1500), (1, 1100), (2, 1300), (3, 2049), (700, 1029)]:
+        img = synth.synth_page(w, max(h, 40), 1, seed=h + w, noise_sigma=5.0, line_div=6)[0][:h]
+        img = np.ascontiguousarray(img)
+        got, exp = run_gpu(img, 51, 51, 0.34), run_cpu(img, 51, 51, 0.34)
+        assert np.array_equal(got, exp), (counted, h, w, int((got != exp).sum()))
+        assert np.array_equal(mrc.threshold_image(img, None), O.threshold_image(img, None))
+    for (pw, ph, seed) in [(1301, 333, 5), (2051, 270, 6)]:
+        img, hocr = synth.synth_page(pw, ph, 3, seed=seed, noise_sigma=5.0, line_div=8)
+        g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='fast', bg_downsample=3)
+        e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', bg_downsample=3)
+        for k, (a, b) in enumerate(zip(g, e)):
+            assert a.shape == b.shape and np.array_equal(a, b), (counted, pw, k)
+
+
 def _headline_page(w, h, seed):
     """a page whose hOCR has page-like boxes: the whole page, a tall headline, long lines, a light-on-dark banner"""
     img, _ = synth.synth_page(w, h, 1, seed=seed, noise_sigma=5.0, line_div=18)

@@ -28,6 +28,19 @@ for i in range(i0, i1):
         inasm = False
     elif inasm and t.startswith('global_load'):
         pending.append((regs_of(t.split(',')[0]), i))
+    elif t.startswith(('global_store', 'buffer_store')) and not t.startswith('global_store_lds'):
+        # a store (asm or the compiler's) is a vm operation like a load: vmcnt retires them in issue order, so it takes a
+        # place in the queue (k_sauvola.hip's counted stores put a fixed number of them between a load and its wait)
+        rs = set()
+        if not inasm:
+            for s_ in t.split(None, 1)[1].split(','):
+                rs |= regs_of(s_)
+            for regs, li in pending:
+                if rs & regs:
+                    bad += 1
+                    if bad <= 20:
+                        print('line %d: %s   <- registers of the load at line %d' % (i - i0, t, li - i0))
+        pending.append((set(), i))
     elif inasm and t.startswith('s_waitcnt') and 'vmcnt' in t:
         n = int(re.search(r'vmcnt\((\d+)\)', t).group(1))
         pending = pending[-n:] if n > 0 else []
@@ -45,5 +58,11 @@ for i in range(i0, i1):
                 bad += 1
                 if bad <= 20:
                     print('line %d: %s   <- registers of the load at line %d' % (i - i0, t, li - i0))
+        # a register the compiler overwrites holds a new value from here on: later reads are not reads of the load's
+        # target (the linear scan runs through loops that never follow each other at run time)
+        if not op.startswith(('global_store', 'ds_write', 'scratch_store', 'buffer_store', 's_', 'v_cmp')):
+            wr = regs_of(parts[0])
+            if wr:
+                pending = [(regs - wr, li) for regs, li in pending]
 print('reads of registers with an asm load in flight: %d' % bad)
 sys.exit(1 if bad else 0)
