@@ -45,6 +45,29 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_table(mrchip_ctx *ctx, double k, doubl
     return 0;
 }
 
+MRCHIP_EXPORT int mrchip_selftest_gauss_fast(mrchip_ctx *ctx, const double *weights, int radius, long long *mismatches,
+                                             double *max_error) {
+    if (!ctx || !weights || !mismatches || radius < 1 || radius > 2) { set_error("selftest_gauss_fast: radius 1 or 2"); return MRCHIP_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    DevBuf gw, res;
+    TRY(gw.alloc(ctx, sizeof(GaussW)));
+    TRY(res.alloc(ctx, 64));
+    GaussW G;
+    memset(&G, 0, sizeof(G));
+    G.radius = radius;
+    for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
+    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    TRY(gauss_fast_selftest(ctx, s, gw.as<GaussW>(), res.as<unsigned long long>(), res.as<unsigned>() + 4));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, res.p, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *mismatches = (long long)h[0];
+    if (max_error) { const unsigned bits = (unsigned)(h[2] & 0xffffffffu); float f; memcpy(&f, &bits, 4); *max_error = (double)f; }
+    return 0;
+}
+
 MRCHIP_EXPORT int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches) {
     CHECK_CTX(ctx);
     if (!mismatches) { set_error("selftest: bad arguments"); return MRCHIP_E_ARG; }

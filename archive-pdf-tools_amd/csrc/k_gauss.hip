@@ -91,15 +91,14 @@ __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpit
 constexpr int GF_TW = 240, GF_TH = 16, GF_RMAX = 8, GF_LW = GF_TW + 2 * GF_RMAX + 4, GF_SEG = 4, GF_THREADS = 256, GF_GROUPS = 64;
 
 template <int R>
-__global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
-                                                                 uint8_t *dst, int dpitch, size_t dstride, int w, int h,
-                                                                 const GaussW *Gs) {
-    __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];   // GF_LW % 4 == 0: rows stay 16-B aligned
-    src += (size_t)blockIdx.z * sstride;
-    dst += (size_t)blockIdx.z * dstride;
-    const GaussW &G = Gs[blockIdx.z];              // padded to radius R by the host
+__device__ __forceinline__ void gauss_fused_tile(float (&tmpT)[GF_TH][GF_LW], const uint8_t *src, int spitch, size_t sstride,
+                                                 uint8_t *dst, int dpitch, size_t dstride, int w, int h, const GaussW *Gs,
+                                                 const int bx, const int by, const int bz) {
+    src += (size_t)bz * sstride;
+    dst += (size_t)bz * dstride;
+    const GaussW &G = Gs[bz];              // padded to radius R by the host
     const int tid = threadIdx.x;
-    const int X0 = blockIdx.x * GF_TW, Y0 = blockIdx.y * GF_TH;
+    const int X0 = bx * GF_TW, Y0 = by * GF_TH;
     const int Xa = max(0, X0 - R) & ~3;                       // first tile column, dword aligned
     const int Xe = min(w, X0 + GF_TW + R);                    // one past the last needed column
     const int ngroups = (Xe - Xa + 3) >> 2;                   // <= 64
@@ -207,6 +206,385 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *
     }
 }
 
+template <int R>
+__global__ __launch_bounds__(GF_THREADS) void gauss_fused_kernel(const uint8_t *src, int spitch, size_t sstride,
+                                                                 uint8_t *dst, int dpitch, size_t dstride, int w, int h,
+                                                                 const GaussW *Gs) {
+    __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];   // GF_LW % 4 == 0: rows stay 16-B aligned
+    gauss_fused_tile<R>(tmpT, src, spitch, sstride, dst, dpitch, dstride, w, h, Gs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- the fast form: both passes in float32, the few pixels it cannot decide in float64 afterwards ------------------
+// The reference's result is b = trunc(fl32(A)), A = the float64 horizontal sum over float32 intermediates v = fl32(V),
+// V = the float64 vertical sum (scipy: float32 array between the axes, mrc.py:309-311 / 325).  gauss_fast_kernel
+// evaluates the same two sums in float32 (round to nearest, one rounding per multiply / add / fma; packed: two pixels per
+// instruction).  With u = 2^-17 (half an ulp of a float32 in [128, 256): every partial sum is < 256 because the weights
+// are positive and sum to 1) and 255 2^-24 < 2^-16 for the weights' own rounding:
+//     vertical:    |v~ - V| <= (R + 1) u + 2^-16   (R + 1 roundings, weights),  |v - V| <= u
+//                  =>  |v~ - v| <= e1(R) = (R + 2) u + 2^-16      -- checked EXHAUSTIVELY for R <= 2 over every (centre,
+//                                                                     pair sum, pair sum): mrchip_selftest_gauss_fast
+//     horizontal:  |a - A| <= (R + 1) u   (roundings of the running sum)  +  u   (pair sums < 512 round by <= 2^-16, times
+//                  the one-sided weights' sum <= 1/2)  +  2^-16 (weights)  +  e1 (the inputs' error, passed through by weights
+//                  that sum to 1)  =  (2 R + 4) u + 2^-15      -- sampled 2^28 times by the same self-test
+//     fl32(A) differs from A by <= u, so a pixel whose a lies further than D(R) = (2 R + 5) u + 2^-15 from every integer
+//     has trunc(a) = b.
+// The kernel takes GQ_E(R) = (2 R + 12) u  (R = 2: 1.22e-4 against D = 9.9e-5; R = 8: 2.14e-4 against 1.91e-4) and works on
+// y = a - 1/2 (the -1/2 rides in the first fma): the byte is v_cvt_pk_u8_f32(y) -- round to nearest even of a - 1/2 = the
+// floor away from ties, saturating, dropped into place -- and a pixel is undecided iff |fract(y) - 1/2| < GQ_E.  Those --
+// 2 GQ_E = 0.024 % of the pixels of a noisy page at R = 2 -- are listed per tile and recomputed by gauss_fix_kernel with
+// the reference's float64 sequence.  A tile with more than GQ_CAP of them (flat areas: a constant window gives an integer)
+// is marked and redone whole by the float64 tile code (gauss_exact_tiles_kernel).  Every tile owns GQ_CAP slots and one
+// count word (0xffffffff = redo the tile): nothing can overflow, and no launch-wide counter is hammered (a first
+// version appended to one global list: 1.5 million same-address atomics per launch cost more than the blur).
+constexpr float gq_e(int R) { return (float)(2 * R + 12) / 131072.0f; }
+constexpr int GQ_CAP = 32;
+constexpr int GQ_INLINE_R = 3;        // radii whose float64 pixel code is small enough to ride inside the fast kernel
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float ub(unsigned v, int e) { return (float)((v >> (8 * e)) & 0xffu); }      // v_cvt_f32_ubyteN
+
+// one pixel with the reference's float64 sequence (G padded to radius R).  Away from the image border its (2R+1)^2
+// neighbourhood comes in as whole dwords, all issued before the first use.
+template <int R>
+__device__ __forceinline__ void gauss_fix_pixel(const uint8_t *sp, int spitch, uint8_t *dp, int dpitch, int w, int h, const GaussW &G,
+                                                const int x, const int y) {
+    double wt[R + 1];
+#pragma unroll
+    for (int k = 0; k <= R; k++) wt[k] = G.w[k];
+    float v[2 * R + 1];
+    if (x >= R && x + R < w && y >= R && y + R < h) {
+        // rows y-R .. y+R, bytes x-R .. x+R of each: aligned dwords (rows are padded), realigned to the first column
+        constexpr int NE = (2 * R + 1 + 3) / 4;         // dwords of 2R+1 bytes
+        const int xa = (x - R) & ~3;
+        const unsigned sh = (unsigned)((x - R) & 3);
+        unsigned d[2 * R + 1][NE + 1];
+#pragma unroll
+        for (int r = 0; r <= 2 * R; r++) {
+            const unsigned *rp = reinterpret_cast<const unsigned *>(sp + (size_t)(y - R + r) * spitch + xa);
+#pragma unroll
+            for (int k = 0; k <= NE; k++) d[r][k] = rp[k];
+        }
+        unsigned eb[2 * R + 1][NE];
+#pragma unroll
+        for (int r = 0; r <= 2 * R; r++)
+#pragma unroll
+            for (int k = 0; k < NE; k++) eb[r][k] = __builtin_amdgcn_alignbyte(d[r][k + 1], d[r][k], sh);
+        auto px = [&](int r, int cidx) { return (eb[r][cidx >> 2] >> (8 * (cidx & 3))) & 0xffu; };
+#pragma unroll
+        for (int cidx = 0; cidx <= 2 * R; cidx++) {
+            double a = __dmul_rn((double)px(R, cidx), wt[R]);
+#pragma unroll
+            for (int j = R; j >= 1; j--) a = __dadd_rn(a, __dmul_rn((double)(px(R - j, cidx) + px(R + j, cidx)), wt[R - j]));
+            v[cidx] = (float)a;
+        }
+    } else {
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            const uint8_t *col = sp + reflect_once(x + dx, w);          // (w, h >= 2 * GF_RMAX: one reflection at most)
+            double a = __dmul_rn((double)col[(size_t)y * spitch], wt[R]);
+#pragma unroll
+            for (int j = R; j >= 1; j--) {
+                const unsigned p = col[(size_t)reflect_once(y - j, h) * spitch], q = col[(size_t)reflect_once(y + j, h) * spitch];
+                a = __dadd_rn(a, __dmul_rn((double)(p + q), wt[R - j]));
+            }
+            v[dx + R] = (float)a;
+        }
+    }
+    double acc = __dmul_rn((double)v[R], wt[R]);
+#pragma unroll
+    for (int j = R; j >= 1; j--) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)v[R - j], (double)v[R + j]), wt[R - j]));
+    dp[(size_t)y * dpitch + x] = (uint8_t)(float)acc;
+}
+
+template <int R>
+__global__ __launch_bounds__(GF_THREADS) void gauss_fast_kernel(const uint8_t *src, int spitch, size_t sstride,
+                                                                uint8_t *dst, int dpitch, size_t dstride, int w, int h,
+                                                                const GaussW *Gs, unsigned *tcnt, unsigned *tslots) {
+    __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];
+    __shared__ unsigned lst[GQ_CAP];
+    __shared__ unsigned lcnt;
+    src += (size_t)blockIdx.z * sstride;
+    dst += (size_t)blockIdx.z * dstride;
+    const GaussW &G = Gs[blockIdx.z];              // padded to radius R by the host
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * GF_TW, Y0 = blockIdx.y * GF_TH;
+    const int Xa = max(0, X0 - R) & ~3;
+    const int Xe = min(w, X0 + GF_TW + R);
+    const int ngroups = (Xe - Xa + 3) >> 2;
+    const int nrows = min(GF_TH, h - Y0);
+    const unsigned tile_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) lcnt = 0;
+    if (G.w[R] == 1.0) {
+        if (tid == 0) tcnt[tile_id] = 0;
+        // a page that is not blurred (radius 0, padded): float32(u8) -> u8 is the identity.  (In float32 every pixel
+        // would come out an exact integer, i.e. undecided.)
+        for (int i = tid; i < nrows * (GF_TW / 4); i += GF_THREADS) {
+            const int ty = i / (GF_TW / 4), x0 = X0 + 4 * (i % (GF_TW / 4));
+            if (x0 >= w) continue;
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + (size_t)(Y0 + ty) * spitch + x0);
+            uint8_t *o = dst + (size_t)(Y0 + ty) * dpitch + x0;
+            if (x0 + 4 <= w) *reinterpret_cast<unsigned *>(o) = v;
+            else for (int k = 0; x0 + k < w; k++) o[k] = (uint8_t)(v >> (8 * k));
+        }
+        return;
+    }
+    float wt[R + 1];
+#pragma unroll
+    for (int k = 0; k <= R; k++) wt[k] = (float)G.w[k];
+    // ---- vertical pass in float32: global -> LDS tile (same lane mapping as the float64 tile code) ----
+    {
+        const int g = tid % GF_GROUPS, sgm = tid / GF_GROUPS;
+        if (g < ngroups && sgm < GF_TH / GF_SEG) {
+            const int x = Xa + 4 * g, y0 = Y0 + sgm * GF_SEG;
+            unsigned in[GF_SEG + 2 * R];
+            if (Y0 - R >= 0 && Y0 + GF_TH + R <= h) {
+                const uint8_t *p = src + (size_t)(y0 - R) * spitch + x;
+#pragma unroll
+                for (int i = 0; i < GF_SEG + 2 * R; i++) in[i] = *reinterpret_cast<const unsigned *>(p + (size_t)i * spitch);
+            } else {
+#pragma unroll
+                for (int i = 0; i < GF_SEG + 2 * R; i++) {
+                    const int yy = reflect_once(min(y0 - R + i, h - 1 + R), h);
+                    in[i] = *reinterpret_cast<const unsigned *>(src + (size_t)yy * spitch + x);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GF_SEG; k++) {
+                if (y0 + k < h) {
+                    const unsigned c = in[k + R];
+                    f32x2 a01 = f32x2{ub(c, 0), ub(c, 1)} * wt[R], a23 = f32x2{ub(c, 2), ub(c, 3)} * wt[R];
+#pragma unroll
+                    for (int j = R; j >= 1; j--) {
+                        const unsigned p = in[k + R - j], q = in[k + R + j];
+                        const f32x2 s01 = f32x2{ub(p, 0), ub(p, 1)} + f32x2{ub(q, 0), ub(q, 1)};     // exact: integers <= 510
+                        const f32x2 s23 = f32x2{ub(p, 2), ub(p, 3)} + f32x2{ub(q, 2), ub(q, 3)};
+                        const f32x2 wj = f32x2{wt[R - j], wt[R - j]};
+                        a01 = __builtin_elementwise_fma(s01, wj, a01);
+                        a23 = __builtin_elementwise_fma(s23, wj, a23);
+                    }
+                    *reinterpret_cast<float4 *>(&tmpT[sgm * GF_SEG + k][4 * g]) = make_float4(a01.x, a01.y, a23.x, a23.y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass in float32: LDS -> bytes; undecided pixels into the workgroup's list ----
+    {
+        constexpr int RP = (R <= 4) ? 4 : 8;
+        const int q = tid & 63, sgm = tid >> 6;
+        const int x0 = X0 + 4 * q;
+        if (q < GF_TW / 4 && x0 < w) {
+            const bool interior = (x0 - R >= 0) && (x0 + 3 + R < w);
+            auto finish_row = [&](int ty, const float (&v)[4 + 2 * RP]) {
+                const f32x2 mhalf = f32x2{-0.5f, -0.5f}, wc = f32x2{wt[R], wt[R]};
+                f32x2 y01 = __builtin_elementwise_fma(f32x2{v[RP], v[RP + 1]}, wc, mhalf);
+                f32x2 y23 = __builtin_elementwise_fma(f32x2{v[RP + 2], v[RP + 3]}, wc, mhalf);
+#pragma unroll
+                for (int j = R; j >= 1; j--) {
+                    const f32x2 wj = f32x2{wt[R - j], wt[R - j]};
+                    y01 = __builtin_elementwise_fma(f32x2{v[RP - j], v[RP + 1 - j]} + f32x2{v[RP + j], v[RP + 1 + j]}, wj, y01);
+                    y23 = __builtin_elementwise_fma(f32x2{v[RP + 2 - j], v[RP + 3 - j]} + f32x2{v[RP + 2 + j], v[RP + 3 + j]}, wj, y23);
+                }
+                const float y[4] = {y01.x, y01.y, y23.x, y23.y};
+                unsigned packed = 0, amb = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(y[e], e, packed);
+                    amb |= (__builtin_fabsf(__builtin_amdgcn_fractf(y[e]) - 0.5f) < gq_e(R)) ? (1u << e) : 0u;
+                }
+                uint8_t *o = dst + (size_t)(Y0 + ty) * dpitch + x0;
+                if (x0 + 4 <= w) *reinterpret_cast<unsigned *>(o) = packed;
+                else for (int i = 0; x0 + i < w; i++) o[i] = (uint8_t)(packed >> (8 * i));
+                if (amb) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (((amb >> e) & 1u) && x0 + e < w) {
+                            const unsigned k = atomicAdd(&lcnt, 1u);
+                            if (k < (unsigned)GQ_CAP) lst[k] = ((unsigned)ty << 8) | (unsigned)(4 * q + e);
+                        }
+                }
+            };
+            if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+                const int off = (x0 - RP - Xa) & ~3;
+#pragma unroll 2
+                for (int k = 0; k < GF_SEG; k++) {
+                    const int ty = sgm * GF_SEG + k;
+                    if (ty >= nrows) break;
+                    const float *seg = static_cast<const float *>(__builtin_assume_aligned(&tmpT[ty][off], 16));
+                    float v[4 + 2 * RP];
+#pragma unroll
+                    for (int i = 0; i < (4 + 2 * RP) / 4; i++) {
+                        const float4 f = *reinterpret_cast<const float4 *>(seg + 4 * i);
+                        v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                    }
+                    finish_row(ty, v);
+                }
+            } else {
+                for (int k = 0; k < GF_SEG; k++) {
+                    const int ty = sgm * GF_SEG + k;
+                    if (ty >= nrows) break;
+                    const float *row = &tmpT[ty][0] - Xa;
+                    float v[4 + 2 * RP];
+#pragma unroll
+                    for (int i = 0; i < 4 + 2 * RP; i++) v[i] = 0.0f;
+#pragma unroll
+                    for (int i = RP - R; i < 4 + RP + R; i++) v[i] = row[reflect_once(x0 - RP + i, w)];
+                    finish_row(ty, v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned n = lcnt;
+    if constexpr (R <= GQ_INLINE_R) {
+        // the undecided pixels right here, while the tile's rows are still in the caches (as a pass of its own the scattered
+        // 128-byte reads from HBM cost 0.19 ms per 128 pages -- a fifth of the blur): n lanes of the first wave
+        if (tid == 0) tcnt[tile_id] = n > (unsigned)GQ_CAP ? 0xffffffffu : 0u;
+        if ((unsigned)tid < n && n <= (unsigned)GQ_CAP) {
+            const unsigned e = lst[tid];
+            // (the byte this lane rewrites was stored by another wave of this workgroup before the barrier above)
+            gauss_fix_pixel<R>(src, spitch, dst, dpitch, w, h, G, X0 + (int)(e & 0xffu), Y0 + (int)(e >> 8));
+        }
+    } else {
+        if (tid == 0) tcnt[tile_id] = n > (unsigned)GQ_CAP ? 0xffffffffu : n;
+        if ((unsigned)tid < n && n <= (unsigned)GQ_CAP) tslots[(size_t)tile_id * GQ_CAP + tid] = lst[tid];     // (row << 8) | column inside the tile
+    }
+}
+
+// The listed pixels with the reference's float64 sequence (the weights table is padded to radius R), one lane each.  A
+// tile lists ~4 of its 3840 pixels: a workgroup takes 256 tiles at a time, scans their counts and hands entry i of the
+// concatenated lists to lane i mod 256 -- full waves (with a lane per slot 7 of 8 lanes idled).  A pixel away from the
+// image border loads its (2R+1)^2 neighbourhood as whole dwords, all issued before the first use (as byte loads in a loop
+// over runtime bounds, weights fetched per tap, this clean-up cost 0.7 ms per 128 pages -- half the blur).
+template <int R>
+__global__ __launch_bounds__(256) void gauss_fix_kernel(const uint8_t *src, int spitch, size_t sstride, uint8_t *dst, int dpitch,
+                                                        size_t dstride, int w, int h, const GaussW *Gs, const unsigned *tcnt,
+                                                        const unsigned *tslots, unsigned ntiles, int gx, int gy) {
+    __shared__ unsigned pre[2][256];
+    __shared__ unsigned total;
+    const int tid = threadIdx.x;
+    for (unsigned chunk = blockIdx.x; chunk * 256u < ntiles; chunk += gridDim.x) {
+        const unsigned t0 = chunk * 256u + tid;
+        unsigned c = t0 < ntiles ? tcnt[t0] : 0u;
+        if (c == 0xffffffffu) c = 0u;                       // a marked tile is redone whole
+        // inclusive scan over the 256 counts (Hillis-Steele in LDS, double buffered)
+        int cur = 0;
+        pre[0][tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const unsigned v = pre[cur][tid] + (tid >= d ? pre[cur][tid - d] : 0u);
+            pre[cur ^ 1][tid] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (tid == 255) total = pre[cur][255];
+        __syncthreads();
+        const unsigned T = total;
+        for (unsigned i = tid; i < T; i += 256) {
+            // the tile whose entries cover i: the first k with inclusive[k] > i
+            int lo = 0, hi = 255;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pre[cur][mid] > i) hi = mid; else lo = mid + 1;
+            }
+            const unsigned t = chunk * 256u + (unsigned)lo;
+            const unsigned slot = i - (lo ? pre[cur][lo - 1] : 0u);
+            const unsigned e = tslots[(size_t)t * GQ_CAP + slot];
+            const int bx = (int)(t % (unsigned)gx), by = (int)((t / (unsigned)gx) % (unsigned)gy), page = (int)(t / ((unsigned)gx * (unsigned)gy));
+            const int y = by * GF_TH + (int)(e >> 8), x = bx * GF_TW + (int)(e & 0xffu);
+            gauss_fix_pixel<R>(src + (size_t)page * sstride, spitch, dst + (size_t)page * dstride, dpitch, w, h, Gs[page], x, y);
+        }
+        __syncthreads();
+    }
+}
+
+// the marked tiles with the float64 tile code: every workgroup scans its share of the count words (normally none is marked)
+template <int R>
+__global__ __launch_bounds__(GF_THREADS) void gauss_exact_tiles_kernel(const uint8_t *src, int spitch, size_t sstride,
+                                                                       uint8_t *dst, int dpitch, size_t dstride, int w, int h,
+                                                                       const GaussW *Gs, const unsigned *tcnt, unsigned ntiles,
+                                                                       int gx, int gy) {
+    __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];
+    __shared__ unsigned marked[GF_THREADS];
+    __shared__ unsigned nmarked;
+    for (unsigned base = blockIdx.x * GF_THREADS; base < ntiles; base += gridDim.x * GF_THREADS) {
+        if (threadIdx.x == 0) nmarked = 0;
+        __syncthreads();
+        const unsigned t = base + threadIdx.x;
+        if (t < ntiles && tcnt[t] == 0xffffffffu) marked[atomicAdd(&nmarked, 1u)] = t;
+        __syncthreads();
+        const unsigned nm = nmarked;
+        for (unsigned i = 0; i < nm; i++) {
+            const unsigned tt = marked[i];
+            gauss_fused_tile<R>(tmpT, src, spitch, sstride, dst, dpitch, dstride, w, h, Gs, (int)(tt % (unsigned)gx),
+                                (int)((tt / (unsigned)gx) % (unsigned)gy), (int)(tt / ((unsigned)gx * (unsigned)gy)));
+            __syncthreads();
+        }
+    }
+}
+
+// Self-test of the vertical stage's error bound e1 (see above) for a table of radius <= 2: every (centre byte, pair sum,
+// pair sum) -- 256 x 511 x 511 -- through the float32 sequence of gauss_fast_kernel and through the float64 one.
+__global__ __launch_bounds__(256) void gauss_fast_selftest_kernel(const GaussW *Gs, unsigned long long *bad, unsigned *maxerr_bits) {
+    const GaussW &G = Gs[0];
+    const int R = G.radius;                      // 1 or 2
+    const float w0 = (float)G.w[R], w1 = (float)G.w[R - 1], w2 = R >= 2 ? (float)G.w[R - 2] : 0.0f;
+    const float e1 = (float)(R + 2) * (1.0f / 131072.0f) + 255.0f / 16777216.0f;
+    const int c = blockIdx.x;                    // centre byte
+    unsigned long long nbad = 0;
+    float worst = 0.0f;
+    for (int s1 = threadIdx.x; s1 <= 510; s1 += 256)
+        for (int s2 = 0; s2 <= (R >= 2 ? 510 : 0); s2++) {
+            float a = (float)c * w0;
+            if (R >= 2) a = __builtin_fmaf((float)s2, w2, a);          // outermost pair first, as in the kernel
+            a = __builtin_fmaf((float)s1, w1, a);
+            double d = __dmul_rn((double)c, G.w[R]);
+            if (R >= 2) d = __dadd_rn(d, __dmul_rn((double)s2, G.w[R - 2]));
+            d = __dadd_rn(d, __dmul_rn((double)s1, G.w[R - 1]));
+            const float err = __builtin_fabsf(a - (float)d);
+            worst = __builtin_fmaxf(worst, err);
+            nbad += err > e1;
+        }
+    // the horizontal stage, sampled: float32 intermediates v (the reference's), the kernel's inputs v~ = v +- e1 at worst,
+    // the kernel's float32 sequence against the float64 sum over v: |a - A| <= (2 R + 4) u + 2^-15
+    {
+        const float bound = (float)(2 * R + 4) / 131072.0f + 1.0f / 32768.0f;
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * 256 + threadIdx.x + 1);
+        auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+        for (int it = 0; it < 4096; it++) {
+            float v[5], vt[5];
+            const unsigned mode = rnd() & 3u;                       // smooth, rough, near-flat, extremes
+            const float base = (float)(rnd() % 256u);
+            for (int i = 0; i < 5; i++) {
+                float x = mode == 0 ? base + (float)(rnd() % 1024u) / 64.0f - 8.0f : mode == 1 ? (float)(rnd() % 65536u) / 257.0f
+                          : mode == 2 ? base + (float)(rnd() % 16u) / 65536.0f : ((rnd() & 1u) ? 255.0f : 0.0f);
+                x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 255.0f);
+                v[i] = x;
+                const float d = (rnd() & 1u) ? e1 : -e1;
+                vt[i] = __builtin_fminf(__builtin_fmaxf(x + ((rnd() & 3u) ? d : 0.0f), 0.0f), 255.0f);
+            }
+            float a = __builtin_fmaf(vt[2], w0, -0.5f);
+            if (R >= 2) a = __builtin_fmaf(vt[0] + vt[4], w2, a);
+            a = __builtin_fmaf(vt[1] + vt[3], w1, a);
+            double A = __dmul_rn((double)v[2], G.w[R]);
+            if (R >= 2) A = __dadd_rn(A, __dmul_rn(__dadd_rn((double)v[0], (double)v[4]), G.w[R - 2]));
+            A = __dadd_rn(A, __dmul_rn(__dadd_rn((double)v[1], (double)v[3]), G.w[R - 1]));
+            const float err = __builtin_fabsf((float)((double)a + 0.5 - A));
+            nbad += err > bound;
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+    atomicMax(maxerr_bits, __float_as_uint(worst));
+}
+
+int gauss_fast_selftest(mrchip_ctx *ctx, hipStream_t s, const GaussW *d_w, unsigned long long *d_bad, unsigned *d_maxerr) {
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(d_maxerr, 0, 4, s));
+    hipLaunchKernelGGL(gauss_fast_selftest_kernel, dim3(256), dim3(256), 0, s, d_w, d_bad, d_maxerr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // true when launch_gaussian_batch will take the fused kernel, i.e. the tables must be padded
 bool gauss_uses_fused(int w, int h, int max_radius) {
     return max_radius >= 1 && max_radius <= GF_RMAX && w >= 2 * GF_RMAX && h >= 2 * GF_RMAX;
@@ -253,6 +631,34 @@ int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, 
     if (max_radius >= 1 && max_radius <= GF_RMAX && w >= 2 * GF_RMAX && h >= 2 * GF_RMAX) {
         // d_weights must be padded to max_radius (gauss_pad_weights)
         dim3 gridf(cdiv(w, GF_TW), cdiv(h, GF_TH), npages);
+        // the float32 form + its two clean-up launches, with the lists in the float scratch the two-pass kernels would
+        // use (MRCHIP_GAUSS_FAST=0: the float64 tile kernel everywhere; the parity tests run both)
+        const char *fast_env = getenv("MRCHIP_GAUSS_FAST");
+        const size_t ntiles = (size_t)gridf.x * gridf.y * gridf.z;
+        const size_t tmp_bytes = (npages > 1 ? tstride * (size_t)npages : (size_t)tpitch * h) * sizeof(float);
+        const size_t need = ntiles * ((size_t)GQ_CAP + 1) * 4;
+        if (!(fast_env && atoi(fast_env) == 0) && tmp && need <= tmp_bytes && ntiles < (1u << 31)) {
+            unsigned *tcnt = reinterpret_cast<unsigned *>(tmp);                 // one count word per tile, written by every tile
+            unsigned *tslots = tcnt + ntiles;                                   // GQ_CAP slots per tile
+            const int cus = ctx->cus > 0 ? ctx->cus : 256;
+            const int gx = (int)gridf.x, gy = (int)gridf.y;
+#define GQ_CASE(RR)                                                                                              \
+    case RR:                                                                                                     \
+        LAUNCH(ctx, s, "gauss_fused", 2.0 * w * h * npages,                                                      \
+               hipLaunchKernelGGL(gauss_fast_kernel<RR>, gridf, dim3(GF_THREADS), 0, s, src.p, src.pitch, src.stride, \
+                                  dst.p, dst.pitch, dst.stride, w, h, d_weights, tcnt, tslots));                  \
+        if (RR > GQ_INLINE_R)                                                                                     \
+        LAUNCH(ctx, s, "gauss_fix", 0.0,                                                                          \
+               hipLaunchKernelGGL(gauss_fix_kernel<RR>, dim3(std::min<size_t>((ntiles + 255) / 256, (size_t)cus * 8)), dim3(256), 0, s, src.p, src.pitch, src.stride, dst.p, \
+                                  dst.pitch, dst.stride, w, h, d_weights, tcnt, tslots, (unsigned)ntiles, gx, gy)); \
+        LAUNCH(ctx, s, "gauss_redo", 0.0,                                                                         \
+               hipLaunchKernelGGL(gauss_exact_tiles_kernel<RR>, dim3(cus), dim3(GF_THREADS), 0, s, src.p, src.pitch, \
+                                  src.stride, dst.p, dst.pitch, dst.stride, w, h, d_weights, tcnt, (unsigned)ntiles, gx, gy)); \
+        break;
+            switch (max_radius) { GQ_CASE(1) GQ_CASE(2) GQ_CASE(3) GQ_CASE(4) GQ_CASE(5) GQ_CASE(6) GQ_CASE(7) GQ_CASE(8) }
+#undef GQ_CASE
+            return 0;
+        }
 #define GF_CASE(RR)                                                                                              \
     case RR:                                                                                                     \
         LAUNCH(ctx, s, "gauss_fused", 2.0 * w * h * npages,                                                      \

@@ -326,6 +326,7 @@ constexpr int GMAXR = 60;
 struct GaussW { double w[2 * GMAXR + 1]; int radius; int pad_; };
 // d_weights: npages GaussW records (radius 0 = identity); tmp: page i at tmp + i*tstride floats
 bool gauss_uses_fused(int w, int h, int max_radius);
+int gauss_fast_selftest(mrchip_ctx *ctx, hipStream_t s, const GaussW *d_w, unsigned long long *d_bad, unsigned *d_maxerr);
 void gauss_pad_weights(GaussW &g, int R);
 // max_radius: the largest radius among the pages (host knows it): <= 8 takes the fused LDS kernel,
 // which expects every page's table padded to max_radius (gauss_pad_weights)

@@ -107,6 +107,7 @@ SIGNATURES = {
     'mrchip_selftest_sauvola_table': (C.c_int, [vp, C.c_double, C.c_double, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                                 C.POINTER(C.c_int)]),
     'mrchip_selftest_optimise_quotients': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
+    'mrchip_selftest_gauss_fast': (C.c_int, [vp, f64p, C.c_int, C.POINTER(C.c_longlong), f64p]),
 }
 
 

@@ -240,6 +240,12 @@ int mrchip_selftest_sauvola_table(mrchip_ctx *ctx, double k, double R, long long
 /* Same for mrchip_optimise's `val / cnt` (cython/optimiser.pyx:261-269): every count 1..5120 (n_size <= 32)
  * against every value 0..255*count. */
 int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long *mismatches);
+/* Device self-test of the float32 form of the Gaussian pre-blur (scipy.ndimage.gaussian_filter at mrc.py:309-311): for a
+ * weights table of radius 1 or 2 (2 * radius + 1 doubles, as scipy builds it), every (centre byte, pair sum, pair sum)
+ * through the kernel's float32 vertical sum and through the reference's float64 one; *mismatches = the number of triples
+ * whose difference exceeds the bound the undecided-pixel test is derived from (must be 0), *max_error = the largest
+ * difference seen. */
+int mrchip_selftest_gauss_fast(mrchip_ctx *ctx, const double *weights, int radius, long long *mismatches, double *max_error);
 
 /* ---- page sharding across GPUs: control-plane collectives over RCCL ---------------------------------------
  * Pages are independent (recode.py:291's loop body reads only page idx): one process per GPU, page i -> rank

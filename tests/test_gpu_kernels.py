@@ -166,6 +166,55 @@ def test_gaussian_golden_and_random():
         assert np.array_equal(out, O.gaussian_filter(g.astype(np.float32), sig, weights=wl).astype(np.uint8))
 
 
+@pytest.mark.parametrize('fast', ['0', '1'])
+def test_gaussian_float32_form_and_float64_form_agree_with_the_oracle(fast, monkeypatch):
+    """The blur runs in float32 with the pixels it cannot decide (result within 2^-11 of an integer: ~0.1 % on noise)
+    listed and recomputed in float64, and tiles with more than 32 of them -- flat areas, where the result IS an integer --
+    redone whole by the float64 tile code; MRCHIP_GAUSS_FAST=0 takes the float64 tile kernel everywhere.  Noise, flat
+    pages (every tile goes to the tile list), two-level art, smooth ramps (long runs of near-integers), a flat page with
+    a few specks (tiles with 1 .. 40 undecided pixels: both lists in one launch), every radius, ragged sizes."""
+    monkeypatch.setenv('MRCHIP_GAUSS_FAST', fast)
+    lib, ctx = lib_ctx()
+    rng = np.random.RandomState(21)
+    h, w = 203, 1021
+    yy, xx = np.mgrid[0:h, 0:w]
+    specks = np.full((h, w), 200, np.uint8)
+    for k in range(60):
+        specks[rng.randint(0, h), rng.randint(0, w)] = rng.randint(0, 256)
+    specks[40:48, 100:340] = rng.randint(190, 211, (8, 240))
+    imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8), np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8),
+            np.full((h, w), 77, np.uint8), np.where((xx // 5 + yy // 3) % 2 == 0, 0, 255).astype(np.uint8),
+            ((xx + 2 * yy) // 3 % 256).astype(np.uint8), (xx * 255 // (w - 1)).astype(np.uint8), specks,
+            np.clip(rng.normal(225, 6, (h, w)), 0, 255).astype(np.uint8)]
+    for sig in (0.3, 0.6, 0.9, 1.2, 1.9):
+        wts, radius = mrc.gaussian_weights(sig)
+        for i, g in enumerate(imgs):
+            out = np.empty_like(g)
+            _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
+            exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
+            assert np.array_equal(out, exp), (fast, sig, i, int((out != exp).sum()), np.argwhere(out != exp)[:4].tolist())
+    for (hh, ww) in [(16, 16), (17, 241), (33, 479), (16, 3000)]:
+        g = rng.randint(0, 256, (hh, ww)).astype(np.uint8)
+        wts, radius = mrc.gaussian_weights(0.6)
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), ww, hh, 0.6, _lib.ptr(wts, _lib.f64p), radius))
+        assert np.array_equal(out, O.gaussian_filter(g.astype(np.float32), 0.6, weights=wts).astype(np.uint8)), (fast, hh, ww)
+
+
+@pytest.mark.parametrize('sig', [0.3, 0.45, 0.6])
+def test_gaussian_float32_vertical_sum_stays_inside_its_bound_exhaustively(sig):
+    """Device self-test: for scipy's table of radius 1 / 2 every (centre, pair sum, pair sum) -- 256 x 511 (x 511) -- through
+    the kernel's float32 vertical sum and the reference's float64 one: the difference never exceeds e1 = (R + 2) 2^-17 +
+    255 2^-24, the figure the 2^-11 undecided band of the float32 form is derived from (k_gauss.hip)."""
+    import ctypes as C
+    wts, radius = mrc.gaussian_weights(sig)
+    assert radius in (1, 2)
+    bad, worst = C.c_longlong(-1), C.c_double(-1.0)
+    _lib.check(_lib.load().mrchip_selftest_gauss_fast(_lib.default_context().handle, _lib.ptr(wts, _lib.f64p), radius, C.byref(bad),
+                                                      C.byref(worst)))
+    assert bad.value == 0 and 0.0 < worst.value <= (radius + 2) * 2.0 ** -17 + 255 * 2.0 ** -24, (bad.value, worst.value)
+
+
 def test_thumbnail_golden_and_random():
     z, cases = thirdparty_cases('thumb')
     lib, ctx = lib_ctx()
