@@ -1348,7 +1348,12 @@ __device__ __forceinline__ T load_uniform(const T *p) {
 }
 
 // Walkers: one workgroup per CU takes entries off the queue until it is empty.
-template <int C, int NH, int MAXT, bool DB>
+// PAGES: the launch holds nothing but the pipeline's page-layers -- n = 3 jobs that are one whole-page band by
+// construction (fg: row flags given, mask not inverted) and n = 10 jobs -- so only three instances of the row loop are
+// compiled in instead of six.  (With six, the 1024-thread RGB kernel ran out of scalar registers and spilled 31 vector
+// registers, some reloaded inside the row loops; with three, 7 launch-lifetime values are spilled at entry and reloaded
+// once per queue entry, none in a row loop: tests/test_isa_checks.py.)
+template <int C, int NH, int MAXT, bool DB, bool PAGES = false>
 __global__ __launch_bounds__(MAXT) void optimise_band_kernel(const OptJob *jobs, const OptBand *q, unsigned *qctl, int njobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_idx;
@@ -1378,7 +1383,12 @@ __global__ __launch_bounds__(MAXT) void optimise_band_kernel(const OptJob *jobs,
         // computes and stores all h rows, and another band of the same job walked at the same time by another workgroup
         // would have its rows written twice with no ordering (identical bytes, but not a pattern to rely on).
         const OptBand *bp = ((B.y1 - B.y0) * 10 >= J.h * 9 && B.c0 == 0 && B.c1 == J.h) ? nullptr : &B;
-        if (bp) {
+        if constexpr (PAGES) {
+            static_assert(!PAGES || NH == 2, "page-layer launches: n = 3 and n = 10");
+            if (bp) optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
+            else if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem, NOSTRIP, 0, 0, nullptr, zero);
+            else optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, nullptr, zero);
+        } else if (bp) {
             if (J.n == 3) optimise_packed_rows<C, 1, 3, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
             else if (J.n == 10 && NH == 2) optimise_packed_rows<C, 2, 10, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
             else optimise_packed_rows<C, NH, -1, DB, true>(J, smem, NOSTRIP, 0, 0, bp, zero);
@@ -1632,12 +1642,23 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         // one walker per CU when the rows need more than half a CU's threads or LDS, else two
         const int per_cu = (g.T <= 512 && 2 * plds <= 160 * 1024) ? 2 : 1;
         const int walkers = std::min<long long>((long long)cap, (long long)cus * per_cu);
-#define OPT_BAND2(CC, NHH, MT, DBB, NAME)                                                                \
+        // page-layer launches (every n = 3 job a whole-page band by construction, everything else n = 10): the kernel
+        // instance with three row loops instead of six
+        static const bool no_pages = getenv("MRCHIP_OPT_PAGES") && atoi(getenv("MRCHIP_OPT_PAGES")) == 0;
+        bool pages_only = n_max == 10 && !no_pages;
+        for (int i = 0; i < njobs && pages_only; i++)
+            pages_only = (h_jobs[i].n == 3 && h_jobs[i].rowflags && !h_jobs[i].invert) || h_jobs[i].n == 10;
+#define OPT_BAND3(CC, NHH, MT, DBB, PG, NAME)                                                            \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_band_kernel<CC, NHH, MT, DBB>), \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(optimise_band_kernel<CC, NHH, MT, DBB, PG>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));            \
         LAUNCH(ctx, s, NAME, alg,                                                                       \
-               hipLaunchKernelGGL((optimise_band_kernel<CC, NHH, MT, DBB>), dim3(walkers), dim3(g.T), plds, s, d_jobs, q, qctl, njobs)); \
+               hipLaunchKernelGGL((optimise_band_kernel<CC, NHH, MT, DBB, PG>), dim3(walkers), dim3(g.T), plds, s, d_jobs, q, qctl, njobs)); \
+    } while (0)
+#define OPT_BAND2(CC, NHH, MT, DBB, NAME)                                                                \
+    do {                                                                                                \
+        if constexpr (NHH == 2) { if (pages_only) OPT_BAND3(CC, NHH, MT, DBB, true, NAME); else OPT_BAND3(CC, NHH, MT, DBB, false, NAME); } \
+        else OPT_BAND3(CC, NHH, MT, DBB, false, NAME);                                                   \
     } while (0)
 #define OPT_BAND(CC, NHH, MT, NAME)                                                                      \
     do { if (db) OPT_BAND2(CC, NHH, MT, true, NAME); else OPT_BAND2(CC, NHH, MT, false, NAME); } while (0)
@@ -1650,6 +1671,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         }
 #undef OPT_BAND
 #undef OPT_BAND2
+#undef OPT_BAND3
     } else if (g.P == 4 && n_max <= 11) {
         // 16-bit lane capacity: one FIR accumulator up to n=8, two halves up to n=11
         if (c == 3) {

@@ -64,3 +64,26 @@ def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
                 'sauvola_kernelILi16ELb0ELb1ELi32E'):
         rc, out = _scan(lst, key)
         assert rc == 0, (key, out[-1500:])
+
+
+def test_the_page_layer_optimise_kernel_spills_nothing_inside_its_row_loops(tmp_path):
+    """optimise_band_kernel<3, 2, 1024, true> -- THE kernel of configs[1] -- carried 26 spilled VGPRs,
+    some reloaded behind loop labels.  Page-layer launches now take the instance with three row loops instead of six
+    (PAGES): a few launch-lifetime values are spilled at entry and reloaded once per queue entry (loop depth 1 = the
+    walker's loop over bands); no scratch access inside a row loop (depth >= 2)."""
+    lst = _listing(tmp_path, 'k_optimise')
+    lines = open(lst).read().split('\n')
+    key = 'optimise_band_kernelILi3ELi2ELi1024ELb1ELb1E'
+    assert _scratch_of(lst, key) <= 32
+    i0 = next(i for i, l in enumerate(lines) if l.startswith('_Z') and key in l.split(':')[0])
+    i1 = next(i for i in range(i0, len(lines)) if lines[i].strip().startswith('.Lfunc_end'))
+    label, deep = '', []
+    for i in range(i0, i1):
+        t = lines[i].strip()
+        if re.match(r'^\.LBB\d+_\d+:', t):
+            label = t
+        elif t.startswith('scratch_'):
+            m = re.search(r'Depth=(\d+)', label)
+            if m and int(m.group(1)) >= 2:
+                deep.append((i - i0, label[:60], t[:50]))
+    assert not deep, deep[:5]
