@@ -59,6 +59,11 @@ def note(*a):
 
 while time.time() - t0 < budget:
     what = rng.randint(17)
+    # round 5: the two forms of the Gaussian (float32 + float64 fix-up / float64) and of the page kernel's stores
+    # (counted asm stores / the compiler's) are read per launch: a case in five runs the other form
+    for _var in ('MRCHIP_GAUSS_FAST', 'MRCHIP_SAUVOLA_COUNTED_STORES'):
+        if rng.rand() < 0.2: os.environ[_var] = '0'
+        else: os.environ.pop(_var, None)
     if what == 0:       # sauvola
         h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
         ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
