@@ -200,3 +200,34 @@ def test_round4_bench_lines():
         g = json.loads(f.read().strip().splitlines()[-1])
     assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
     assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
+
+
+def test_round5_bench_lines():
+    """The lines of round 5 (profiles/r05_README.md): the driver's command on the committed head, the three other
+    configurations (one gpurun call each), the eight-rank rehearsal on one GPU."""
+    with open(os.path.join(ROOT, 'profiles', 'r05_bench_c2.json')) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'pipeline_frac', 'head', 'srchash'):
+        assert key in d, key
+    assert d['value'] > 10000 and d['unit'] == 'pages/s' and d['vs_baseline'] is None and d['dtype'] == 'u8' and d['n_gpus'] == 1
+    assert d['head'] and len(d['head']) >= 12 and not d['head'].endswith('+') and d['srchash']      # built from a clean, committed tree
+    r = d['roofline']
+    assert r['kernel'] == 'optimise_rgb' and r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / 8000.0) < 1e-4 and 'isolated' in r
+    assert r['isolated']['frac'] > 0.45 and d['sauvola_roofline']['isolated']['frac'] > 0.23
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and not c.get('error') and c['value'] > 10
+    assert c['memory_capped'] is True and c['cores'] <= 64 and c['worker_peak_rss_GB'] < 1.0 and c['host_memory']['cgroup_limit_GB'] > 300
+    assert d['parity']['mismatches'] == 0 and d['parity']['pages_checked'] == 16
+    assert d['config4_stack']['mismatches'] == 0 and d['config4_stack']['all_pages_present']
+    assert d['rccl_ok'] is True and 'gauss_fix' not in d['kernels'] and 'gauss_redo' in d['kernels']      # radius 2: the fix rides inside the blur
+    for cfg, unit, least, pages in (('c3', 'pages/s', 5000, 4), ('c3gray', 'GB/s', 1500, 8), ('c5', 'pages/s', 1900, 2)):
+        with open(os.path.join(ROOT, 'profiles', 'r05_bench_%s.json' % cfg)) as f:
+            x = json.loads(f.read().strip().splitlines()[-1])
+        assert x['unit'] == unit and x['value'] > least and x['parity']['mismatches'] == 0 and x['parity']['pages_checked'] == pages
+        assert x['cpu_baseline'] is None and x['head'] and x['roofline']['bound'] == 'hbm'
+    with open(os.path.join(ROOT, 'profiles', 'r05_bench_gpus8_on_one_gpu.json')) as f:
+        g = json.loads(f.read().strip().splitlines()[-1])
+    assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
+    assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
+    assert g['parity']['pages_checked'] == 128
