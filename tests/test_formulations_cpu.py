@@ -148,3 +148,55 @@ def test_bench_memory_budget_respects_a_cgroup_limit(tmp_path, monkeypatch):
     with open('/proc/meminfo') as f:
         avail = [int(ln.split()[1]) * 1024 for ln in f if ln.startswith('MemAvailable')][0]
     assert b <= avail * 1.05
+
+
+# ---- round 5: the Gaussian pre-blur in float32 with an undecided band (k_gauss.hip, gauss_fast_kernel) -------------------
+def _fma32(a, b, c):
+    """float32 fma: the product of two float32 is exact in float64; one rounding of the sum to float32 (the float64 sum is
+    within 2^-53 relative of the real one: far inside the float32 half-ulp except at exact ties, which the bound absorbs)"""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _gauss_fast_model(g, wts):
+    """the kernel's float32 sequence on a whole image (reflect borders): returns y = a - 1/2 as float32"""
+    R = (len(wts) - 1) // 2
+    w32 = wts.astype(np.float32)
+    h, w = g.shape
+    gp = np.pad(g, ((R, R), (0, 0)), mode='symmetric').astype(np.float32)
+    v = gp[R:R + h] * w32[R]                                     # v_pk_mul_f32
+    for j in range(R, 0, -1):
+        s = gp[R - j:R - j + h] + gp[R + j:R + j + h]            # exact: integers <= 510
+        v = _fma32(s, np.broadcast_to(w32[R - j], s.shape), v)
+    vp = np.pad(v, ((0, 0), (R, R)), mode='symmetric')
+    y = _fma32(vp[:, R:R + w], np.broadcast_to(w32[R], (h, w)), np.full((h, w), -0.5, np.float32))
+    for j in range(R, 0, -1):
+        t = (vp[:, R - j:R - j + w] + vp[:, R + j:R + j + w]).astype(np.float32)     # v_pk_add_f32: one rounding
+        y = _fma32(t, np.broadcast_to(w32[R - j], t.shape), y)
+    return y
+
+
+@pytest.mark.parametrize('sig', [0.3, 0.6, 0.9, 1.2, 1.9])
+def test_gaussian_float32_model_decides_like_the_oracle_outside_its_band(sig):
+    """|a - A| <= (2R+4) 2^-17 + 2^-15 for the float32 sequence against the reference's float64 one (checked here on images:
+    noise, flats, ramps, two-level art), and wherever |fract(a - 1/2) - 1/2| >= E(R) = (2R+12) 2^-17 the byte
+    round-half-even(a - 1/2) IS the reference's trunc(float32(A)) -- the pixels the GPU kernel does not recompute."""
+    from mrchip import mrc
+    wts, R = mrc.gaussian_weights(sig)
+    rng = np.random.RandomState(int(sig * 10))
+    h, w = 96, 700
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8), np.clip(rng.normal(225, 6, (h, w)), 0, 255).astype(np.uint8),
+            np.full((h, w), 255, np.uint8), np.full((h, w), 131, np.uint8), (xx * 255 // (w - 1)).astype(np.uint8),
+            np.where((xx // 5 + yy // 3) % 2 == 0, 0, 255).astype(np.uint8), ((3 * xx + 7 * yy) % 256).astype(np.uint8)]
+    E = (2 * R + 12) * 2.0 ** -17
+    bound = (2 * R + 4) * 2.0 ** -17 + 2.0 ** -15
+    for g in imgs:
+        exact32 = O.gaussian_filter(g.astype(np.float32), sig, weights=wts)          # float32(A): the reference before its truncation
+        y = _gauss_fast_model(g, wts).astype(np.float64)
+        a = y + 0.5
+        assert np.abs(a - exact32.astype(np.float64)).max() <= bound + 2.0 ** -17     # (float32(A) is within 2^-17 of A)
+        decided = np.abs((y - np.floor(y)) - 0.5) >= E
+        byte = np.clip(np.rint(y), 0, 255).astype(np.uint8)                           # v_cvt_pk_u8_f32: nearest even, saturating
+        assert np.array_equal(byte[decided], exact32.astype(np.uint8)[decided])
+        if g is imgs[0] or g is imgs[1]:
+            assert decided.mean() > 0.999                                            # the band is thin on noise (flat cells give integers)
