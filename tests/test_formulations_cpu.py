@@ -199,4 +199,4 @@ def test_gaussian_float32_model_decides_like_the_oracle_outside_its_band(sig):
         byte = np.clip(np.rint(y), 0, 255).astype(np.uint8)                           # v_cvt_pk_u8_f32: nearest even, saturating
         assert np.array_equal(byte[decided], exact32.astype(np.uint8)[decided])
         if g is imgs[0] or g is imgs[1]:
-            assert decided.mean() > 0.999                                            # the band is thin on noise (flat cells give integers)
+            assert decided.mean() > 0.99                                             # the band is thin on noise (sigma 0.3: weights 0.004 | 0.992 | 0.004, results hug the integers: 0.5 %)
