@@ -238,3 +238,32 @@ def test_timing_data_carries_measured_stage_times():
     assert ctx.prof_on and 'optimise_rgb' in ctx.prof_report()
     ctx.prof_enable(False)
     assert [k for k, _ in td2] == [k for k in keys if k != 'fg_downsample']
+
+
+def test_device_memory_report_and_the_reserve_guard():
+    """mrchip_device_memory reports hipMemGetInfo; an allocation that would leave less than MRCHIP_HBM_RESERVE_BYTES of device
+    memory free is refused with an error (MRCHIP_E_NOMEM) BEFORE hipMalloc is asked -- round 5's guard against driving a box
+    out of memory.  The reserve is read once per process: a child process with a reserve larger than the device."""
+    import subprocess
+    import sys
+    import os
+    ctx = _lib.default_context()
+    free, total = ctx.memory()
+    assert 0 < free <= total and total > (64 << 30)                      # an MI355X: 288 GB
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mrchip import _lib, mrc\n"
+        "ctx = _lib.default_context()\n"
+        "small = mrc.Batch(ctx, 1, 256, 256, 3); small.close()           # blocks below 64 MiB are not checked\n"
+        "try:\n"
+        "    mrc.Batch(ctx, 4, 4000, 3000, 3)\n"
+        "    print('ALLOCATED')\n"
+        "except _lib.MrchipError as e:\n"
+        "    print('REFUSED', e)\n" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'archive-pdf-tools_amd'))
+    env = dict(os.environ, MRCHIP_HBM_RESERVE_BYTES=str(total + (1 << 30)))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert 'REFUSED' in r.stdout and 'kept in reserve' in r.stdout and 'ALLOCATED' not in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ALLOCATED' in r.stdout, (r.stdout, r.stderr[-800:])
