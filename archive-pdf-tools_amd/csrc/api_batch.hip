@@ -299,7 +299,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
             hj[i].dst_inv = b->thB.as<uint8_t>() + 256 + bi.off + bi.phase;
             hj[i].dst_pitch = bi.pitch;
             hj[i].counts = dcounts + 2 * i;
-            hj[i].bits = nullptr; hj[i].bits_pitch = 0;
+            hj[i].bits = nullptr; hj[i].bits_pitch = 0; hj[i].no_bytes = 0;
         }
         HIP_TRY(hipMemsetAsync(dcounts, 0, (size_t)nb * 8, s));
         HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nb * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
@@ -443,6 +443,7 @@ static int box_decisions_commit(mrchip_batch *b, int or_mode) {
                          ? reinterpret_cast<uint8_t *>(b->dn_bits.as<unsigned>() + (size_t)bi.page * b->dn_stride + (size_t)cdiv(b->w, 32) * b->h)
                          : nullptr;
         hb[i].bits_pitch = cdiv(b->w, 32) * 4;
+        hb[i].no_bytes = hb[i].bits != nullptr;      // commit_bits: the denoiser's unpack rewrites the mask bytes from the bit rows
         for (int j = i + 1; j < hb[i].page_end; j++) {
             const BoxInfo &bj = b->boxes[j];
             if (bj.decision && bj.l < bi.r && bi.l < bj.r && bj.t < bi.b && bi.t < bj.b) { hb[i].overlapped = 1; break; }
@@ -522,6 +523,9 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         // the denoiser's ORIGINAL rows: second half of the page's bit scratch
         hj[i].bits = fuse_bits ? reinterpret_cast<uint8_t *>(b->dn_bits.as<unsigned>() + (size_t)i * b->dn_stride + (size_t)wpr * h) : nullptr;
         hj[i].bits_pitch = wpr * 4;
+        // with the bit rows written here and by the commit, nothing reads the mask BYTES before the denoiser's unpack
+        // rewrites them: they are not stored (1 byte per pixel less to write, 2 less to read-modify-write per box pixel)
+        hj[i].no_bytes = fuse_bits ? 1 : 0;
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, b->window, b->window, 0.34, 128.0, SAUVOLA_INVERT));   // :325-329 (stored, not OR-ed)
@@ -561,7 +565,7 @@ MRCHIP_EXPORT int mrchip_batch_threshold(mrchip_batch *b, int window, double k) 
         hj[i].w = b->w; hj[i].h = b->h;
         hj[i].dst = b->mask.pl.page(i); hj[i].dst_pitch = b->mask.pl.pitch;
         hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
-        hj[i].bits = nullptr; hj[i].bits_pitch = 0;
+        hj[i].bits = nullptr; hj[i].bits_pitch = 0; hj[i].no_bytes = 0;
     }
     HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, window, window, k, 128.0, SAUVOLA_INVERT));

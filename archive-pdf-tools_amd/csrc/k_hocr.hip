@@ -36,6 +36,13 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
             // or_mode: the mask already holds the page threshold (mrc.py:329's OR, applied first); each pixel has
             // exactly one owner (box, lane), so the read-modify-write is race-free
             u32x4 v = *(gc_u4p)(uintptr_t)tp;
+            if (B.bits && B.no_bytes) {
+                // only the 1-bpp rows carry the mask at this point (the bytes are rewritten from them after the denoiser):
+                // the lane owns these 16 bits, which hold the page threshold -- OR the box threshold in
+                const g_u16p bp = (g_u16p)(uintptr_t)(B.bits + (size_t)py * B.bits_pitch + (xa0 >> 3));
+                *bp = (unsigned short)(*bp | nib01(v.x) | nib01(v.y) << 4 | nib01(v.z) << 8 | nib01(v.w) << 12);
+                continue;
+            }
             if (or_mode) v |= *(gc_u4p)(uintptr_t)mp;
             *(g_u4p)(uintptr_t)mp = v;
             if (B.bits) {
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256) void hocr_commit_kernel(const HocrBox *boxes, 
                     if ((keep >> (8 * i)) & 0xffu) tv |= (unsigned)(tp[4 * q + i] & 1u) << i;
                 if (tv) atomicOr(reinterpret_cast<unsigned *>(B.bits + (size_t)py * B.bits_pitch) + (xa >> 5), tv << (xa & 31));
             }
+            if (B.bits && B.no_bytes) continue;       // (the bit rows have it: see above)
             uint8_t *mq8 = mp + 4 * q;
             if (keep == 0xffffffffu) {
                 const unsigned v = *reinterpret_cast<const unsigned *>(tp + 4 * q);

@@ -678,8 +678,15 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
         if (!act) return;
         uint8_t *o = out + (size_t)yy * opitch + (size_t)x0 * C;
         if (x0 + P <= XE) {
+            if constexpr (NCT >= 8 || NCT < 0) {
+                // wide windows (the bg layer, n = 10): the row is re-read once, 11 rows later, by which time sixteen walkers per XCD
+                // have pushed it out of the 4 MB L2 anyway -- stored non-temporally it does not evict the image rows on its way
 #pragma unroll
-            for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+                for (int q = 0; q < ND; q++) __builtin_nontemporal_store(res[q], (unsigned *)(uintptr_t)((g_u32p)o + q));
+            } else {
+#pragma unroll
+                for (int q = 0; q < ND; q++) ((g_u32p)o)[q] = res[q];
+            }
         } else {
             const int nbytes = (XE - x0) * C;
 #pragma unroll

@@ -365,10 +365,12 @@ __device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const Sauvol
         static_assert(NST == 0 || KD == 2, "counted stores: the 8-column kernel");
         if constexpr (NST > 0) {
             unsigned long long saved;
-            u32x2 dv = u32x2{ov[0], ov[KD - 1]};
             rowp = uniform_ptr(rowp); brow = uniform_ptr(brow);
-            asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, %4\n\ts_mov_b64 exec, %0"
-                         : "=&s"(saved) : "s"(valid_mask), "v"(loff), "v"(dv), "s"(rowp) : "memory", "scc");
+            if constexpr (NST != 3) {         // NST: 1 = the bytes, 2 = bytes and bit row, 3 = the bit row only (SauvolaJob::no_bytes)
+                u32x2 dv = u32x2{ov[0], ov[KD - 1]};
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %3, %4\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(valid_mask), "v"(loff), "v"(dv), "s"(rowp) : "memory", "scc");
+            }
             if constexpr (NST > 1) {
                 const unsigned boff = (unsigned)lane;
                 asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_byte %2, %3, %4\n\ts_mov_b64 exec, %0"
@@ -397,8 +399,9 @@ __device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const Sauvol
     // are the compiler's (a varying number): leaving them out of N makes the wait stricter than needed -- it then also
     // waits for the acknowledgement of stores two rows old and for loads issued one row ago, which is what the
     // counted stores are for (128 pages 4000x3000: 1.93 -> 1.66 ms with the stores removed altogether).
-    constexpr int WAIT_EL = 3 * (PF - 1) + 1 + NST * PF;     // vm operations issued after row y's e/l pair: c(y), the stores of row y-PF, then PF-1 whole rows
-    constexpr int WAIT_C = 3 * (PF - 1) + 2 + NST * PF;      // ... after c(y): the same, plus e(y+PF), l(y+PF)
+    constexpr int NSTC = NST == 2 ? 2 : (NST ? 1 : 0);     // store INSTRUCTIONS per row
+    constexpr int WAIT_EL = 3 * (PF - 1) + 1 + NSTC * PF;     // vm operations issued after row y's e/l pair: c(y), the stores of row y-PF, then PF-1 whole rows
+    constexpr int WAIT_C = 3 * (PF - 1) + 2 + NSTC * PF;      // ... after c(y): the same, plus e(y+PF), l(y+PF)
 
     unsigned ones_a = 0, ones_b = 0;
     const bool kpos = P.k >= 0;
@@ -879,6 +882,11 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
                 (want_bits && !j.bits) || (j.bits && j.bits_pitch < cdiv(j.w, 8)))
                 nst = 0;
         }
+        if (nst == 2) {                      // every job's bytes unwanted: the bit rows only
+            bool nb = true;
+            for (int i = 0; i < njobs; i++) nb = nb && h_jobs[i].no_bytes;
+            if (nb) nst = 3;
+        }
         const char *cs_env = getenv("MRCHIP_SAUVOLA_COUNTED_STORES");      // (read per launch: the parity tests run both)
         if (cs_env && atoi(cs_env) == 0) nst = 0;
         if (nst) P.two &= ~(K - 1);
@@ -943,8 +951,15 @@ static int launch_k(mrchip_ctx *ctx, hipStream_t s, const SauvolaJob *h_jobs, co
     } while (0)
             if constexpr (K == 8) {
                 if (nst && small_pl) {         // (sel is 0 or 2 here: single polarity)
-                    if (sel == 0) { if (nst == 2) SAUVOLA_TAB_LAUNCH_N(false, false, 8, 2); else SAUVOLA_TAB_LAUNCH_N(false, false, 8, 1); }
-                    else { if (nst == 2) SAUVOLA_TAB_LAUNCH_N(true, false, 8, 2); else SAUVOLA_TAB_LAUNCH_N(true, false, 8, 1); }
+                    if (sel == 0) {
+                        if (nst == 3) SAUVOLA_TAB_LAUNCH_N(false, false, 8, 3);
+                        else if (nst == 2) SAUVOLA_TAB_LAUNCH_N(false, false, 8, 2);
+                        else SAUVOLA_TAB_LAUNCH_N(false, false, 8, 1);
+                    } else {
+                        if (nst == 3) SAUVOLA_TAB_LAUNCH_N(true, false, 8, 3);
+                        else if (nst == 2) SAUVOLA_TAB_LAUNCH_N(true, false, 8, 2);
+                        else SAUVOLA_TAB_LAUNCH_N(true, false, 8, 1);
+                    }
                     return 0;
                 }
             }

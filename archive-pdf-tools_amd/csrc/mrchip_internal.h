@@ -191,6 +191,9 @@ struct SauvolaJob {
     // ceil(w / 8) of a row are never written.
     uint8_t *bits;
     int bits_pitch;       // bytes per row of the bit plane
+    // with bits: the caller does not read `dst` before it rewrites it (the batch's mask bytes are unpacked from the
+    // denoiser's bit rows afterwards): the 8-column page kernel then stores the bit rows only
+    int no_bytes;
 };
 // true when launch_sauvola_dev will take a kernel that can fill SauvolaJob::bits for jobs of this size / window
 bool sauvola_writes_bits(int maxw, int maxh, int ww);
@@ -270,6 +273,7 @@ struct HocrBox {
     int overlapped;          // a later box of the page with a decision intersects this one
     uint8_t *bits;           // optional (or_mode): row 0 of the page's 1-bpp mask rows, OR-ed alongside the bytes
     int bits_pitch;
+    int no_bytes;            // with bits: only the bit rows are updated (the mask bytes are rewritten from them afterwards)
 };
 int launch_hocr_commit(mrchip_ctx *ctx, hipStream_t s, const HocrBox *d_boxes, int nb, int maxw, int maxh, double area,
                        int or_mode);

@@ -42,7 +42,8 @@ def test_sauvola_row_queues_are_never_read_in_flight(tmp_path):
     lst = _listing(tmp_path, 'k_sauvola')
     # the table kernels of pages (8 columns, 16 waves) and hOCR boxes (4 columns, two polarities), the fp64 kernels
     # (the last template argument of the table kernel: stores per row counted into the vmcnt waits -- 0 = the compiler's stores)
-    for key in ('sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi2E', 'sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi1E',
+    for key in ('sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi3E', 'sauvola_tab_kernelILi8ELb0ELb0ELi8ELi16ELi4ELi3E',       # 3: the bit rows only
+                'sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi2E', 'sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi1E',
                 'sauvola_tab_kernelILi8ELb1ELb0ELi8ELi16ELi4ELi0E', 'sauvola_tab_kernelILi8ELb0ELb0ELi8ELi16ELi4ELi2E',
                 'sauvola_tab_kernelILi4ELb1ELb1ELi8ELi8', 'sauvola_tab_kernelILi4ELb1ELb1ELi32ELi8',
                 'sauvola_tab_kernelILi8ELb0ELb0ELi8ELi16ELi4ELi0E', 'sauvola_kernelILi8ELb1ELb0ELi8E', 'sauvola_kernelILi4ELb1ELb1ELi32E',
