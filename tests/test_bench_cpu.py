@@ -217,7 +217,7 @@ def test_round5_bench_lines():
     assert r['isolated']['frac'] > 0.45 and d['sauvola_roofline']['isolated']['frac'] > 0.23
     # counter traffic of THIS build's kernels (profiles/r05_pmc_summary.json records the same source hash)
     assert r['traffic'] and 1.2 < r['traffic'] / r['alg_bytes_per_launch'] < 1.4 and r['traffic_source']['kernel_sources_equal'] is True
-    assert 2.3 < d['sauvola_roofline']['traffic'] / d['sauvola_roofline']['alg_bytes_per_launch'] < 2.8
+    assert 1.8 < d['sauvola_roofline']['traffic'] / d['sauvola_roofline']['alg_bytes_per_launch'] < 2.3      # (2.55 before the page pass stopped storing mask bytes)
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and not c.get('error') and c['value'] > 10
     assert c['memory_capped'] is True and c['cores'] <= 64 and c['worker_peak_rss_GB'] < 1.0 and c['host_memory']['cgroup_limit_GB'] > 300
