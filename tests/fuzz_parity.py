@@ -57,8 +57,23 @@ def note(*a):
     _last.seek(0); _last.truncate(); _last.write(repr(a) + '\n'); _last.flush(); os.fsync(_last.fileno())
 
 
+def _dump_on_failure(tp, val, tb):
+    """a failing case leaves its arrays (inputs, got, expected) and the kernel-form switches in gpurun_out/fuzz_fail_<seed>.npz"""
+    try:
+        keep = {k: v for k, v in globals().items() if isinstance(v, np.ndarray) and v.size < 50_000_000 and not k.startswith('_')}
+        keep['env_switches'] = np.array([os.environ.get('MRCHIP_GAUSS_FAST', ''), os.environ.get('MRCHIP_SAUVOLA_COUNTED_STORES', ''),
+                                         os.environ.get('MRCHIP_OPT_STRIPS', '')])
+        keep['failure'] = np.array([repr(val)])
+        np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'fuzz_fail_%d.npz' % seed), **keep)
+    finally:
+        sys.__excepthook__(tp, val, tb)
+
+
+sys.excepthook = _dump_on_failure
+
 while time.time() - t0 < budget:
     what = rng.randint(17)
+    if os.environ.get('FUZZ_BIAS') and rng.rand() < 0.5: what = int(os.environ['FUZZ_BIAS'])      # half the cases from one family
     # round 5: the two forms of the Gaussian (float32 + float64 fix-up / float64) and of the page kernel's stores
     # (counted asm stores / the compiler's) are read per launch: a case in five runs the other form
     for _var in ('MRCHIP_GAUSS_FAST', 'MRCHIP_SAUVOLA_COUNTED_STORES'):
@@ -240,6 +255,20 @@ while time.time() - t0 < budget:
             wts, _r = mrc.gaussian_weights(sig * 0.1)
             src = O.gaussian_filter(gimg.astype(np.float32), sig * 0.1, weights=wts).astype(np.uint8)
         exp = m0 | O.threshold_image(src, dpi)
+        if not np.array_equal(got, exp):
+            # which stage?  the same inputs through each stage again (a second full run tells a race from a wrong result)
+            gs = mrc.estimate_noise(gimg)
+            print('threshold_mask mismatch: %d px; sigma gpu %r oracle %r' % (int((got != exp).sum()), gs, sig), flush=True)
+            if sig > 1.0:
+                gb = np.empty_like(gimg)
+                _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(gimg), _lib.ptr(gb), w, h, sig * 0.1, _lib.ptr(wts, _lib.f64p), _r))
+                print('  gaussian again: %d px differ from the oracle' % int((gb != src).sum()), np.argwhere(gb != src)[:6].tolist(), flush=True)
+            tb = mrc.threshold_image(src, dpi)
+            print('  threshold of the oracle-blurred image again: %d px differ' % int((tb != O.threshold_image(src, dpi)).sum()), flush=True)
+            again = m0.copy()
+            mrc.create_threshold_mask(again, gimg.astype(np.float32), dpi=dpi)
+            print('  whole call again: %d px differ; first differing px of the failing call' % int((again != exp).sum()),
+                  np.argwhere(got != exp)[:8].tolist(), flush=True)
         assert np.array_equal(got, exp), ('threshold_mask', h, w, dpi)
         tick('threshold_mask')
     elif what == 14:    # optimise, band walkers (whole rows forced): unselected pixels in runs of rows with gaps around n_size
