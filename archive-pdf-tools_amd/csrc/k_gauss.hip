@@ -436,6 +436,15 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fast_kernel(const uint8_t *s
             }
         }
     }
+    // The inline clean-up below rewrites single bytes of dwords that OTHER waves of this workgroup have just stored.  At
+    // workgroup scope the compiler's barrier waits for lgkmcnt only (the listing shows no vmcnt before s_barrier): by the
+    // gfx942 / gfx950 memory model the stores of one CU reach memory in issue order, so the patch cannot overtake the
+    // dword -- but nothing here has to lean on that: every wave sees its own stores acknowledged before it arrives
+    // (+1.8 % on the launch; tests/test_isa_checks.py looks for the wait in the listing).  Tried instead: the undecided
+    // groups kept back and stored once by the recomputing lane, +10 %; every wave patching the pixels of its own rows,
+    // +10 % (the float64 pixel code then runs in up to four waves per tile instead of one); the wait only in the rare
+    // listing branch, +3.8 %.
+    if constexpr (R <= GQ_INLINE_R) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned n = lcnt;
     if constexpr (R <= GQ_INLINE_R) {
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(GF_THREADS) void gauss_fast_kernel(const uint8_t *s
         if (tid == 0) tcnt[tile_id] = n > (unsigned)GQ_CAP ? 0xffffffffu : 0u;
         if ((unsigned)tid < n && n <= (unsigned)GQ_CAP) {
             const unsigned e = lst[tid];
-            // (the byte this lane rewrites was stored by another wave of this workgroup before the barrier above)
+            // (the byte this lane rewrites was stored by another wave of this workgroup, and acknowledged, before the barrier)
             gauss_fix_pixel<R>(src, spitch, dst, dpitch, w, h, G, X0 + (int)(e & 0xffu), Y0 + (int)(e >> 8));
         }
     } else {

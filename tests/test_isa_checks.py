@@ -88,3 +88,22 @@ def test_the_page_layer_optimise_kernel_spills_nothing_inside_its_row_loops(tmp_
             if m and int(m.group(1)) >= 2:
                 deep.append((i - i0, label[:60], t[:50]))
     assert not deep, deep[:5]
+
+
+def test_the_float32_gaussian_sees_its_stores_acknowledged_before_the_in_kernel_clean_up(tmp_path):
+    """gauss_fast_kernel<R <= 3> rewrites, after its second barrier, single bytes of dwords that other waves of the workgroup
+    stored before it.  hipcc's workgroup-scope barrier waits for lgkmcnt only, so the kernel carries its own
+    `s_waitcnt vmcnt(0)` in front of that barrier (k_gauss.hip): the listing must show it, directly before the last
+    s_barrier of the kernel; the radii with a separate fix launch (R >= 4) need none."""
+    lst = _listing(tmp_path, 'k_gauss')
+    lines = open(lst).read().split('\n')
+    for R, wanted in ((1, True), (2, True), (3, True), (4, False), (8, False)):
+        key = 'gauss_fast_kernelILi%dE' % R
+        i0 = next(i for i, l in enumerate(lines) if l.startswith('_Z') and key in l.split(':')[0])
+        i1 = next(i for i in range(i0, len(lines)) if lines[i].strip().startswith('.Lfunc_end'))
+        body = [l.strip() for l in lines[i0:i1] if l.strip() and not l.strip().startswith((';', '.'))]
+        bars = [i for i, t in enumerate(body) if t.startswith('s_barrier')]
+        assert len(bars) >= 2, (key, len(bars))
+        before = body[max(0, bars[-1] - 4):bars[-1]]
+        has = any(t.startswith('s_waitcnt') and 'vmcnt(0)' in t for t in before)
+        assert has == wanted, (key, before)
