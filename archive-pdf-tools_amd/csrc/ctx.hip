@@ -16,17 +16,66 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- guard bands (debug switch MRCHIP_CANARY=<KiB per side>, default off) -----------------------------------------
+// Kernels of this library read AND write the documented slack of their images (row padding, PAD bytes in front of row 0
+// and behind the last row).  With the switch on, every block the allocator hands out carries `guard` more bytes on both
+// sides filled with a pattern; mrchip_canary_check (and every dev_free, for its block) reads them back: a byte that
+// changed is a write outside a block -- into what would be a neighbouring plane of the cache without the guards.
+static size_t canary_bytes() {
+    static const size_t g = [] {
+        const char *e = getenv("MRCHIP_CANARY");
+        long long kib = e ? atoll(e) : 0;
+        if (kib < 0) kib = 0;
+        if (kib > (1 << 16)) kib = 1 << 16;
+        return (size_t)kib << 10;
+    }();
+    return g;
+}
+constexpr unsigned char CANARY_BYTE = 0xC5;
+
+static long long canary_verify_block(mrchip_ctx *ctx, DevBlock &b) {
+    if (!b.guard || !b.base) return 0;
+    std::vector<unsigned char> host(b.guard);
+    long long bad = 0;
+    for (int side = 0; side < 2; side++) {
+        unsigned char *g = (unsigned char *)b.base + (side ? b.bytes - b.guard : 0);
+        if (hipMemcpy(host.data(), g, b.guard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        long long first = -1, n = 0;
+        for (size_t i = 0; i < b.guard; i++)
+            if (host[i] != CANARY_BYTE) { if (first < 0) first = (long long)i; n++; }
+        if (n) {
+            fprintf(stderr, "mrchip canary: %lld byte(s) overwritten in the %s guard of a %zu-byte block (first at guard offset %lld, "
+                            "value 0x%02x)\n", n, side ? "trailing" : "leading", b.bytes - 2 * b.guard, first, host[first]);
+            (void)hipMemset(g, CANARY_BYTE, b.guard);      // report a stray write once
+            bad += n;
+        }
+    }
+    ctx->canary_bad += bad;
+    return bad;
+}
+
+long long canary_check_all(mrchip_ctx *ctx) {
+    long long bad = 0;
+    for (auto &b : ctx->blocks) {
+        const long long n = canary_verify_block(ctx, b);
+        if (n < 0) return -1;
+        bad += n;
+    }
+    return bad;
+}
+
 int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
-    bytes = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;     // never a zero-byte (null) block
+    const size_t guard = canary_bytes();
+    bytes = ((std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095) + 2 * guard;     // never a zero-byte (null) block
     int best = -1;
     for (size_t i = 0; i < ctx->blocks.size(); i++) {
         DevBlock &b = ctx->blocks[i];
-        if (!b.busy && b.bytes >= bytes && b.bytes <= bytes * 2 + (1 << 20))
+        if (!b.busy && b.guard == guard && b.bytes >= bytes && b.bytes <= bytes * 2 + (1 << 20))
             if (best < 0 || b.bytes < ctx->blocks[best].bytes) best = (int)i;
     }
     if (best >= 0) {
         ctx->blocks[best].busy = true;
-        *out = ctx->blocks[best].base;
+        *out = (char *)ctx->blocks[best].base + guard;
         return 0;
     }
     void *p = nullptr;
@@ -36,16 +85,24 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     };
     // A large block is checked against what the device has free BEFORE hipMalloc is asked: an allocation that only
     // just fits leaves the runtime nothing for its own queues and code objects, and what a driver does past that
-    // point is not something a page loop should find out (MRCHIP_HBM_RESERVE_BYTES, default 2 GiB, stays free).
+    // point is not something a page loop should find out (MRCHIP_HBM_RESERVE_BYTES, default 2 GiB, stays free; the
+    // value is clamped to [0, half the device]: a negative or garbage setting must not refuse every large block).
     if (bytes >= ((size_t)64 << 20)) {
-        static const size_t reserve = getenv("MRCHIP_HBM_RESERVE_BYTES") ? (size_t)atoll(getenv("MRCHIP_HBM_RESERVE_BYTES"))
-                                                                         : ((size_t)2 << 30);
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {
-            drop_cache();
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {
-                set_error("device memory: %zu bytes asked, %zu of %zu free (%zu kept in reserve)", bytes, fr, tot, reserve);
-                return MRCHIP_E_NOMEM;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            size_t reserve = (size_t)2 << 30;
+            if (const char *e = getenv("MRCHIP_HBM_RESERVE_BYTES")) {
+                char *end = nullptr;
+                const long long v = strtoll(e, &end, 10);
+                if (end != e && v >= 0) reserve = (size_t)v;
+            }
+            reserve = std::min(reserve, tot / 2);
+            if (bytes + reserve > fr) {
+                drop_cache();
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {
+                    set_error("device memory: %zu bytes asked, %zu of %zu free (%zu kept in reserve)", bytes, fr, tot, reserve);
+                    return MRCHIP_E_NOMEM;
+                }
             }
         }
     }
@@ -58,10 +115,18 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
             return MRCHIP_E_NOMEM;
         }
     }
+    if (guard) {
+        if (hipMemset(p, CANARY_BYTE, guard) != hipSuccess ||
+            hipMemset((char *)p + bytes - guard, CANARY_BYTE, guard) != hipSuccess) {
+            (void)hipFree(p);
+            set_error("canary: hipMemset failed");
+            return MRCHIP_E_HIP;
+        }
+    }
     DevBlock b;
-    b.base = p; b.bytes = bytes; b.busy = true;
+    b.base = p; b.bytes = bytes; b.busy = true; b.guard = guard;
     ctx->blocks.push_back(b);
-    *out = p;
+    *out = (char *)p + guard;
     return 0;
 }
 
@@ -72,7 +137,10 @@ void dev_free(mrchip_ctx *ctx, void *p) {
     static const size_t cap = getenv("MRCHIP_CACHE_BYTES") ? (size_t)atoll(getenv("MRCHIP_CACHE_BYTES")) : ((size_t)16 << 30);
     size_t idle = 0;
     for (auto &b : ctx->blocks) {
-        if (b.base == p) b.busy = false;
+        if (b.base && (char *)b.base + b.guard == p) {
+            if (b.guard) (void)canary_verify_block(ctx, b);      // (callers release scratch with their stream idle)
+            b.busy = false;
+        }
         if (!b.busy && b.base) idle += b.bytes;
     }
     while (idle > cap) {
@@ -226,6 +294,41 @@ MRCHIP_EXPORT int mrchip_sync(mrchip_ctx *ctx) {
     if (!ctx) return MRCHIP_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     for (int i = 0; i < NSTREAMS; i++) HIP_TRY(hipStreamSynchronize(ctx->streams[i]));
+    return 0;
+}
+
+// Guard bands (MRCHIP_CANARY, see dev_alloc): waits for the device, then verifies the guards of every block of the
+// context; *bad_bytes = overwritten guard bytes found since the context was created (0 with the switch off).
+MRCHIP_EXPORT int mrchip_canary_check(mrchip_ctx *ctx, long long *bad_bytes) {
+    if (!ctx) return MRCHIP_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (canary_check_all(ctx) < 0) { set_error("canary: reading a guard band failed"); return MRCHIP_E_HIP; }
+    if (bad_bytes) *bad_bytes = ctx->canary_bad;
+    return 0;
+}
+
+// Proof that the guard bands see a stray write: one byte in front of and one behind a scratch block of its own are
+// overwritten on purpose (inside that block's guards, nowhere else); *detected = guard bytes the verification then
+// reports (2 with the switch on, 0 with it off).  The context's running count is left as it was.
+MRCHIP_EXPORT int mrchip_canary_selftest(mrchip_ctx *ctx, long long *detected) {
+    if (!ctx || !detected) return MRCHIP_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    *detected = 0;
+    const size_t guard = canary_bytes();
+    if (!guard) return 0;
+    void *p = nullptr;
+    TRY(dev_alloc(ctx, 4096, &p));
+    const long long before = ctx->canary_bad;
+    hipError_t e1 = hipMemset((char *)p - 1, 0, 1), e2 = hipMemset((char *)p + 4096, 0, 1);
+    long long n = -1;
+    for (auto &b : ctx->blocks)
+        if (b.base && (char *)b.base + b.guard == p) n = canary_verify_block(ctx, b);
+    ctx->canary_bad = before;
+    dev_free(ctx, p);
+    if (e1 != hipSuccess || e2 != hipSuccess || n < 0) { set_error("canary selftest: device access failed"); return MRCHIP_E_HIP; }
+    *detected = n;
     return 0;
 }
 

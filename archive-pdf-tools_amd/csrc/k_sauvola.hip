@@ -649,12 +649,24 @@ __device__ __forceinline__ void sauvola_tile(const SauvolaJob &job, const Sauvol
             }
         }
     };
-    for (int yb = Y0; yb < Y0 + rows; yb += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; d++)
-            if (yb + d < Y0 + rows) do_row(yb + d, qe[d], ql[d], qc[d]);
+    // A row past the tile's last one LEAVES the loop (it is not skipped inside it): every path through the listing is
+    // then one the program can take.  tools/isa_vmflow.py follows each asm load to its wait along every path of the
+    // control-flow graph; `if (yb + d < end) do_row(..)` inside a `for (yb < end)` loop gave it the path "slot 0, skip
+    // slot 1, slot 0 again", which no tile runs.
+    {
+        static_assert(PF == 2, "the row loop is written out for two slots");
+        const int yend = Y0 + rows;
+        for (int yb = Y0; yb < yend; yb += PF) {
+            do_row(yb, qe[0], ql[0], qc[0]);
+            if (yb + 1 >= yend) break;
+            do_row(yb + 1, qe[1], ql[1], qc[1]);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the queue's last loads (rows past the tile) land before the registers are reused
+    // The queue's last loads (rows past the tile) land before their registers are reused: the wait takes every slot as
+    // an in/out operand, so the compiler keeps the slots allocated up to it -- a bare asm with a "memory" clobber lets the
+    // register allocator hand a dead slot to an ordinary value BEFORE the wait, which the landing load then overwrites.
+    static_assert(PF == 2, "the closing wait names the slots of two rows");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qe[0]), "+v"(ql[0]), "+v"(qc[0]), "+v"(qe[1]), "+v"(ql[1]), "+v"(qc[1]) : : "memory");
     if (job.counts) {
         unsigned a = wave_sum(ones_a);
         unsigned b = wave_sum(ones_b);

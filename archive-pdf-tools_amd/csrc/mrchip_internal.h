@@ -57,8 +57,9 @@ constexpr int PAD = 1024;
 
 struct DevBlock {
     void *base = nullptr;   // hipMalloc'ed
-    size_t bytes = 0;
+    size_t bytes = 0;       // of the whole block, guard bands included
     bool busy = false;
+    size_t guard = 0;       // MRCHIP_CANARY: bytes of pattern on each side; the caller's pointer is base + guard
 };
 
 struct ProfEntry {
@@ -101,6 +102,7 @@ struct mrchip_ctx {
     int cus = 0;
     size_t hbm = 0;
     char name[128] = {};
+    long long canary_bad = 0;     // guard-band bytes found overwritten so far (MRCHIP_CANARY)
 };
 
 namespace mrchip {

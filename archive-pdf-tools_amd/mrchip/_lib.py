@@ -98,6 +98,8 @@ SIGNATURES = {
     'mrchip_comm_bcast': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_int]),
     'mrchip_comm_allgather': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mrchip_comm_allreduce_f64': (C.c_int, [vp, f64p, C.c_int, C.c_int]),
+    'mrchip_canary_check': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
+    'mrchip_canary_selftest': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
     'mrchip_prof_enable': (C.c_int, [vp, C.c_int]),
     'mrchip_prof_reset': (C.c_int, [vp]),
     'mrchip_prof_count': (C.c_int, [vp]),
@@ -170,6 +172,19 @@ class Context:
 
     def sync(self):
         check(load().mrchip_sync(self.handle), 'mrchip_sync')
+
+    def canary_check(self):
+        """Guard bands of the device allocator (MRCHIP_CANARY=<KiB>, a debugging switch): waits for the device, verifies
+        every block, returns the guard bytes found overwritten since the context was created (0 with the switch off)."""
+        n = C.c_longlong()
+        check(load().mrchip_canary_check(self.handle, C.byref(n)), 'mrchip_canary_check')
+        return int(n.value)
+
+    def canary_selftest(self):
+        """-> guard bytes detected after a deliberate one-byte write on each side of a scratch block (2 on, 0 off)."""
+        n = C.c_longlong()
+        check(load().mrchip_canary_selftest(self.handle, C.byref(n)), 'mrchip_canary_selftest')
+        return int(n.value)
 
     def numa_node(self):
         """NUMA node of the socket the GPU is attached to, -1 if unknown."""

@@ -54,6 +54,14 @@ mrchip_ctx *mrchip_create(int device);
 void mrchip_destroy(mrchip_ctx *ctx);
 const char *mrchip_last_error(void);
 int mrchip_sync(mrchip_ctx *ctx);
+/* Debugging aid, no reference counterpart: with MRCHIP_CANARY=<KiB> in the environment every device block of the caching
+ * allocator carries that many KiB of a fixed pattern on both sides (beyond the documented slack the kernels may touch).
+ * This call waits for the device, verifies every guard band and reports on stderr; *bad_bytes = guard bytes found
+ * overwritten since the context was created (always 0 with the switch off).  tests/fuzz_parity.py calls it per case. */
+int mrchip_canary_check(mrchip_ctx *ctx, long long *bad_bytes);
+/* Proof that the guards see a stray write: overwrites one byte on each side of a scratch block of its own (inside that
+ * block's guard bands) and verifies; *detected = 2 with MRCHIP_CANARY on, 0 with it off. */
+int mrchip_canary_selftest(mrchip_ctx *ctx, long long *detected);
 /* Device name / CU count of the context's device (for reports). */
 int mrchip_device_info(mrchip_ctx *ctx, char *name, int name_len, int *cus, size_t *hbm_bytes);
 /* Device memory free / total right now (hipMemGetInfo), for callers that size batches: a batch of N pages holds about

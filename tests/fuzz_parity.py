@@ -1,7 +1,20 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity sweep (kernel entry points and whole-page decompositions over random
 shapes / windows / k / n_size / downsample factors / hOCR boxes).  Not part of the pytest suite (minutes);
-run on a GPU box:  python tests/fuzz_parity.py [seconds] [seed]"""
+run on a GPU box:  python tests/fuzz_parity.py [seconds] [seed]
+
+Environment:
+  FUZZ_MODE=self      GPU-vs-GPU determinism mode (round 6): the checker of every case is the GPU path run AGAIN -- under
+                      another draw of the kernel-form switches (fp64 / table Sauvola decision, counted / compiler stores,
+                      float32 / float64 Gaussian, strips / whole rows, MFMA / VALU and fused / two-pass thumbnails), a
+                      third of the time under the very same forms -- instead of the oracle.  A result that depends on the
+                      run or on the form is a defect whatever the oracle says, and without the (single-threaded C) oracle
+                      a process gets through ~10x the cases per hour.
+  FUZZ_FAMILIES=0,4,13  only these families;  FUZZ_SCALE=0.5  shapes of the Sauvola / Gaussian / threshold-mask / sigma
+                      families scaled down (more launches per second);  FUZZ_BIAS=n  half the cases from family n.
+  FUZZ_INJECT=n       the checker's n-th result is corrupted on purpose: proves that a mismatch is caught and that the
+                      arrays of the failing case land in gpurun_out/fuzz_fail_<seed>.npz.
+  MRCHIP_CANARY=64    (library switch) guard bands around every device block; verified after every case here."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'archive-pdf-tools_amd'))
@@ -16,6 +29,92 @@ rng = np.random.RandomState(seed)
 lib, ctx = _lib.load(), _lib.default_context()
 t0 = time.time()
 counts = {}
+SELF = os.environ.get('FUZZ_MODE') == 'self'
+FAMILIES = [int(x) for x in os.environ['FUZZ_FAMILIES'].split(',')] if os.environ.get('FUZZ_FAMILIES') else list(range(17))
+SCALE = float(os.environ.get('FUZZ_SCALE', '1'))
+INJECT = int(os.environ.get('FUZZ_INJECT', '0'))
+CANARY = bool(os.environ.get('MRCHIP_CANARY'))
+FORM_SWITCHES = (('MRCHIP_GAUSS_FAST', '0'), ('MRCHIP_SAUVOLA_COUNTED_STORES', '0'), ('MRCHIP_SAUVOLA_FAST', '0'),
+                 ('MRCHIP_OPT_STRIPS', '0'), ('MRCHIP_THUMB_NO_MFMA', '1'), ('MRCHIP_THUMB_NO_FUSE', '1'))
+
+
+def sc(n, lo=1):
+    """a drawn dimension under FUZZ_SCALE"""
+    return max(lo, int(n * SCALE))
+
+
+class GpuTwin:
+    """FUZZ_MODE=self: the oracle's functions, answered by the GPU path itself under another draw of the form switches
+    (all of them are read per launch).  `last_env` is what the second run saw; it goes into the dump of a failing case."""
+
+    def __init__(self):
+        self.calls = 0
+        self.last_env = {}
+
+    def _alt(self):
+        keep = {k: os.environ.get(k) for k, _v in FORM_SWITCHES}
+        same = rng.rand() < 0.34
+        for k, v in FORM_SWITCHES:
+            if same:
+                continue                      # the very same forms again: pure run-to-run determinism
+            if rng.rand() < 0.5: os.environ[k] = v
+            else: os.environ.pop(k, None)
+        self.last_env = {k: os.environ.get(k) for k, _v in FORM_SWITCHES}
+        return keep
+
+    def _restore(self, keep):
+        for k, v in keep.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+    def _run(self, fn):
+        keep = self._alt()
+        try:
+            r = fn()
+        finally:
+            self._restore(keep)
+        self.calls += 1
+        if INJECT and self.calls == INJECT:
+            a = r[0] if isinstance(r, list) else r
+            if isinstance(a, np.ndarray) and a.size:
+                a.reshape(-1)[0] ^= 1
+                print('FUZZ_INJECT: corrupted one byte of checker result %d' % self.calls, flush=True)
+        return r
+
+    def binarise_sauvola(self, a, out, w, h, ww, wh, k, R):
+        self._run(lambda: (sauvola.binarise_sauvola(a, out, w, h, ww, wh, k, R), out)[1])
+
+    def optimise_gray2(self, mask, img, w, h, n): return self._run(lambda: optimiser.optimise_gray2(mask, img, w, h, n))
+    def optimise_rgb2(self, mask, img, w, h, n): return self._run(lambda: optimiser.optimise_rgb2(mask, img, w, h, n))
+    def fast_mask_denoise(self, m, w, h, mincnt, n): return self._run(lambda: optimiser.fast_mask_denoise(m, w, h, mincnt, n))
+    def thumbnail_ex(self, img, rw, rh, flt, gap): return self._run(lambda: mrc.thumbnail(img, (rw, rh), resample=flt, reducing_gap=gap))
+
+    def gaussian_filter(self, imgf, sig, weights=None):
+        g = np.ascontiguousarray(imgf, dtype=np.uint8)
+        h, w = g.shape
+        wts, radius = (weights, len(weights) // 2) if weights is not None else mrc.gaussian_weights(sig)
+        out = np.empty_like(g)
+        return self._run(lambda: (_lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig,
+                                                                     _lib.ptr(wts, _lib.f64p), radius)), out)[1])
+
+    def estimate_sigma(self, a): return self._run(lambda: mrc.mean_estimate_sigma(a))
+    def estimate_noise(self, a): return self._run(lambda: mrc.estimate_noise(a))
+    def threshold_image(self, src, dpi, k=0.34): return self._run(lambda: mrc.threshold_image(src, dpi, k))
+
+    def luma601(self, rgb):
+        h, w = rgb.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        src = np.ascontiguousarray(rgb)
+        return self._run(lambda: (_lib.check(lib.mrchip_luma601(ctx.handle, _lib.ptr(src), _lib.ptr(out), w, h)), out)[1])
+
+    def create_mrc_hocr_components(self, img, hocr, **kw):
+        res = self._run(lambda: list(mrc.create_mrc_hocr_components(img, hocr, **kw)))
+        for a in res:
+            yield a
+
+
+if SELF:
+    O = GpuTwin()
 
 
 def tick(name):
@@ -64,6 +163,7 @@ def _dump_on_failure(tp, val, tb):
         keep['env_switches'] = np.array([os.environ.get('MRCHIP_GAUSS_FAST', ''), os.environ.get('MRCHIP_SAUVOLA_COUNTED_STORES', ''),
                                          os.environ.get('MRCHIP_OPT_STRIPS', '')])
         keep['failure'] = np.array([repr(val)])
+        if SELF: keep['twin_env'] = np.array([repr(O.last_env)])
         np.savez_compressed(os.path.join(ROOT, 'gpurun_out', 'fuzz_fail_%d.npz' % seed), **keep)
     finally:
         sys.__excepthook__(tp, val, tb)
@@ -71,16 +171,21 @@ def _dump_on_failure(tp, val, tb):
 
 sys.excepthook = _dump_on_failure
 
+_ncase = 0
 while time.time() - t0 < budget:
-    what = rng.randint(17)
+    if CANARY and _ncase:
+        _bad = ctx.canary_check()
+        assert _bad == 0, ('canary: %d guard byte(s) overwritten by the case before this one' % _bad, open(_last.name).read())
+    _ncase += 1
+    what = int(FAMILIES[rng.randint(len(FAMILIES))])
     if os.environ.get('FUZZ_BIAS') and rng.rand() < 0.5: what = int(os.environ['FUZZ_BIAS'])      # half the cases from one family
     # round 5: the two forms of the Gaussian (float32 + float64 fix-up / float64) and of the page kernel's stores
     # (counted asm stores / the compiler's) are read per launch: a case in five runs the other form
-    for _var in ('MRCHIP_GAUSS_FAST', 'MRCHIP_SAUVOLA_COUNTED_STORES'):
+    for _var in ('MRCHIP_GAUSS_FAST', 'MRCHIP_SAUVOLA_COUNTED_STORES') + (('MRCHIP_SAUVOLA_FAST',) if SELF else ()):
         if rng.rand() < 0.2: os.environ[_var] = '0'
         else: os.environ.pop(_var, None)
     if what == 0:       # sauvola
-        h, w = int(rng.randint(1, 700)), int(rng.randint(1, 1500))
+        h, w = sc(rng.randint(1, 700)), sc(rng.randint(1, 1500))
         ww, wh = int(rng.randint(1, 140)), int(rng.randint(1, 140))
         if rng.rand() < 0.5: wh = ww
         k = float(rng.choice([0.34, 0.1, 0.5, -0.2, 0.0, 1.0])); R = float(rng.choice([128.0, 64.0, 200.0]))
@@ -129,7 +234,7 @@ while time.time() - t0 < budget:
         assert got.shape == exp.shape and np.array_equal(got, exp), ('thumbnail', h, w, c, ds, flt, gap)
         tick('thumbnail')
     elif what == 4:     # gaussian
-        h, w = int(rng.randint(2, 500)), int(rng.randint(2, 1300))
+        h, w = sc(rng.randint(2, 500), 2), sc(rng.randint(2, 1300), 2)
         g = rnd_img(h, w)
         sig = float(rng.choice([0.15, 0.3, 0.45, 0.63, 0.9, 1.3, 2.1, 3.3]))
         wts, radius = mrc.gaussian_weights(sig)
@@ -140,7 +245,7 @@ while time.time() - t0 < budget:
         assert np.array_equal(out, exp), ('gauss', h, w, sig)
         tick('gauss')
     elif what == 6:     # noise estimate entry points (float32 path on uint8 values, float64 path on bool arrays)
-        h, w = int(rng.randint(1, 400)), int(rng.randint(1, 900))
+        h, w = sc(rng.randint(1, 400)), sc(rng.randint(1, 900))
         if rng.rand() < 0.5:
             a = rnd_img(h, w)
             note('sigma_u8', h, w)
@@ -240,7 +345,7 @@ while time.time() - t0 < budget:
         assert n == npg
         tick('stream')
     elif what == 13:    # create_threshold_mask: estimate + blur + Sauvola + in-place OR
-        h, w = int(rng.randint(8, 500)), int(rng.randint(8, 900))
+        h, w = sc(rng.randint(8, 500), 8), sc(rng.randint(8, 900), 8)
         gimg, _ = synth.synth_page(max(w, 64), max(h, 64), 1, seed=int(rng.randint(1 << 30)), noise_sigma=float(rng.choice([0, 3, 8, 20])),
                                    line_div=int(rng.choice([8, 16])))
         gimg = np.ascontiguousarray(gimg[:h, :w])
@@ -359,4 +464,8 @@ while time.time() - t0 < budget:
             a, b = next(g), next(e)
             assert a.shape == b.shape and np.array_equal(a, b), ('page', h, w, c, kw, i)
         tick('page')
-print('fuzz ok: %.0f s, seed %d, cases %s' % (time.time() - t0, seed, counts))
+if CANARY:
+    assert ctx.canary_selftest() == 2, 'the guard bands did not see a deliberate stray write'
+    assert ctx.canary_check() == 0
+print('fuzz ok%s%s: %.0f s, seed %d, %d cases %s' % (' (GPU-vs-GPU, forms redrawn)' if SELF else '', ' (guard bands on)' if CANARY else '',
+                                                  time.time() - t0, seed, sum(counts.values()), counts))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Listing check for kernels with hand-counted asynchronous loads (k_sauvola.hip, k_optimise_ws.hip): an instruction
+"""(Superseded by tools/isa_vmflow.py, which follows the control flow; kept as the quick linear look.)
+Listing check for kernels with hand-counted asynchronous loads (k_sauvola.hip, k_optimise_ws.hip): an instruction
 that READS a register between the asm load that targets it and the asm `s_waitcnt vmcnt(N)` covering it copies or spills
 data that has not landed.  Linear scan per basic-block order (ignores control flow: a hit is a place to look at, not proof).
 usage: isa_inflight.py file.s <substring of the mangled kernel name>"""
