@@ -321,10 +321,15 @@ MRCHIP_EXPORT int mrchip_canary_selftest(mrchip_ctx *ctx, long long *detected) {
     void *p = nullptr;
     TRY(dev_alloc(ctx, 4096, &p));
     const long long before = ctx->canary_bad;
-    hipError_t e1 = hipMemset((char *)p - 1, 0, 1), e2 = hipMemset((char *)p + 4096, 0, 1);
     long long n = -1;
+    hipError_t e1 = hipErrorUnknown, e2 = hipErrorUnknown;
     for (auto &b : ctx->blocks)
-        if (b.base && (char *)b.base + b.guard == p) n = canary_verify_block(ctx, b);
+        if (b.base && (char *)b.base + b.guard == p) {
+            // (a cached block may be larger than what was asked for: its trailing guard starts at its own end)
+            e1 = hipMemset((char *)p - 1, 0, 1);
+            e2 = hipMemset((char *)b.base + b.bytes - b.guard, 0, 1);
+            n = canary_verify_block(ctx, b);
+        }
     ctx->canary_bad = before;
     dev_free(ctx, p);
     if (e1 != hipSuccess || e2 != hipSuccess || n < 0) { set_error("canary selftest: device access failed"); return MRCHIP_E_HIP; }

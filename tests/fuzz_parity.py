@@ -8,8 +8,9 @@ Environment:
                       another draw of the kernel-form switches (fp64 / table Sauvola decision, counted / compiler stores,
                       float32 / float64 Gaussian, strips / whole rows, MFMA / VALU and fused / two-pass thumbnails), a
                       third of the time under the very same forms -- instead of the oracle.  A result that depends on the
-                      run or on the form is a defect whatever the oracle says, and without the (single-threaded C) oracle
-                      a process gets through ~10x the cases per hour.
+                      run or on the form is a defect whatever the oracle says.  (Measured: about the same cases per
+                      second as the oracle mode -- a case's time is host work, not the C oracle -- so a hunt runs many
+                      processes side by side: tools/runs/fuzz_hunt.sh.)
   FUZZ_FAMILIES=0,4,13  only these families;  FUZZ_SCALE=0.5  shapes of the Sauvola / Gaussian / threshold-mask / sigma
                       families scaled down (more launches per second);  FUZZ_BIAS=n  half the cases from family n.
   FUZZ_INJECT=n       the checker's n-th result is corrupted on purpose: proves that a mismatch is caught and that the
