@@ -304,7 +304,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
         HIP_TRY(hipMemsetAsync(dcounts, 0, (size_t)nb * 8, s));
         HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nb * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
         TRY(launch_sauvola_dev(ctx, s, hj, dj, nb, window, window, 0.1, 128.0, SAUVOLA_INVERT));          // mrc.py:229-235
-        HIP_TRY(hipMemcpyAsync(b->hctrl + L.counts, dcounts, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+        TRY(download_1d(s, b->hctrl + L.counts, dcounts, (size_t)nb * 8));
     }
     // ---- noise estimate of the central crop (mrc.py:280-292) ----
     SigJob *hsj = reinterpret_cast<SigJob *>(b->hctrl + L.sigjobs);
@@ -319,7 +319,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
     HIP_TRY(hipMemcpyAsync(dsj, hsj, (size_t)N * sizeof(SigJob), hipMemcpyHostToDevice, s));
     double *dsig = reinterpret_cast<double *>(dctrl + L.sigma);
     TRY(launch_estimate_sigma_jobs(ctx, s, hsj, dsj, N, 0, dsig));
-    HIP_TRY(hipMemcpyAsync(b->hctrl + L.sigma, dsig, (size_t)N * 8, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, b->hctrl + L.sigma, dsig, (size_t)N * 8));
     b->state = 2;
     return 0;
 }
@@ -394,7 +394,7 @@ static int box_decisions_begin(mrchip_batch *b) {
         double *dsig = reinterpret_cast<double *>(dctrl + L.box_sigma);
         HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(SigJob), hipMemcpyHostToDevice, s));
         TRY(launch_estimate_sigma_jobs(ctx, s, hj, dj, nj, 1, dsig));
-        HIP_TRY(hipMemcpyAsync(b->hctrl + L.box_sigma, dsig, (size_t)nj * 8, hipMemcpyDeviceToHost, s));
+        TRY(download_1d(s, b->hctrl + L.box_sigma, dsig, (size_t)nj * 8));
         if (!b->box_ev) HIP_TRY(hipEventCreateWithFlags(&b->box_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(b->box_ev, s));
     }
@@ -499,12 +499,14 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
     }
     Plane thr_src = b->gray;
     if (any_blur) {
+        bool fast_ok = true;
+        for (int i = 0; i < N; i++) fast_ok = fast_ok && gauss_weights_allow_fast(hg[i]);
         if (gauss_uses_fused(w, h, max_radius))
             for (int i = 0; i < N; i++) gauss_pad_weights(hg[i], max_radius);
         GaussW *dg = reinterpret_cast<GaussW *>(dctrl + L.gauss);
         HIP_TRY(hipMemcpyAsync(dg, hg, (size_t)N * sizeof(GaussW), hipMemcpyHostToDevice, s));
         TRY(launch_gaussian_batch(ctx, s, b->gray, b->blur.pl, w, h, dg, b->gtmp.as<float>(), b->gtmp_pitch,
-                                  b->gtmp_stride, N, max_radius));                                       // mrc.py:311, 325
+                                  b->gtmp_stride, N, max_radius, fast_ok));                              // mrc.py:311, 325
         thr_src = b->blur.pl;
     }
     SauvolaJob *hj = reinterpret_cast<SauvolaJob *>(b->hctrl + L.pjobs);
@@ -608,8 +610,7 @@ static int download_mask_packed_impl(mrchip_batch *b, int page, uint8_t *out, bo
         TRY(launch_pack_msb(b->ctx, b->s, b->mask.pl, b->w, b->h, b->packed.as<uint8_t>(), per_page, b->active));
         b->packed_valid = 1;
     }
-    HIP_TRY(hipMemcpyAsync(out, b->packed.as<uint8_t>() + per_page * page, (size_t)((b->w + 7) / 8) * b->h,
-                           hipMemcpyDeviceToHost, b->s));
+    TRY(download_1d(b->s, out, b->packed.as<uint8_t>() + per_page * page, (size_t)((b->w + 7) / 8) * b->h));
     if (wait) HIP_TRY(hipStreamSynchronize(b->s));
     return 0;
 }
@@ -748,7 +749,7 @@ static int download_layer_impl(mrchip_batch *b, int page, int is_bg, uint8_t *ou
     const int c = b->c;
     if (b->layer_small[Lr]) {
         const size_t nbytes = (size_t)b->layer_w[Lr] * b->layer_h[Lr] * c;
-        HIP_TRY(hipMemcpyAsync(out, b->small[Lr].pl.page(page), nbytes, hipMemcpyDeviceToHost, b->s));
+        TRY(download_1d(b->s, out, b->small[Lr].pl.page(page), nbytes));
     } else {
         TRY(download_2d(b->s, out, b->w * c, b->layer[Lr].pl.page(page), b->layer[Lr].pl.pitch, b->w * c, b->h));
     }

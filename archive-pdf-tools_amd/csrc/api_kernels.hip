@@ -22,7 +22,7 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_quotients(mrchip_ctx *ctx, long long *
     TRY(bad.alloc(ctx, 256));
     TRY(sauvola_div_selftest(ctx, s, bad.as<unsigned long long>()));
     unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, &h, bad.p, 8));
     HIP_TRY(hipStreamSynchronize(s));
     *mismatches = (long long)h;
     return 0;
@@ -38,7 +38,7 @@ MRCHIP_EXPORT int mrchip_selftest_sauvola_table(mrchip_ctx *ctx, double k, doubl
     TRY(bad.alloc(ctx, 256));
     TRY(sauvola_table_selftest(ctx, s, k, R, bad.as<unsigned long long>(), table_bytes));
     unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, bad.p, 16, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, h, bad.p, 16));
     HIP_TRY(hipStreamSynchronize(s));
     *mismatches = (long long)h[0];
     *tested = (long long)h[1];
@@ -61,7 +61,7 @@ MRCHIP_EXPORT int mrchip_selftest_gauss_fast(mrchip_ctx *ctx, const double *weig
     HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
     TRY(gauss_fast_selftest(ctx, s, gw.as<GaussW>(), res.as<unsigned long long>(), res.as<unsigned>() + 4));
     unsigned long long h[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, res.p, 32, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, h, res.p, 32));
     HIP_TRY(hipStreamSynchronize(s));
     *mismatches = (long long)h[0];
     if (max_error) { const unsigned bits = (unsigned)(h[2] & 0xffffffffu); float f; memcpy(&f, &bits, 4); *max_error = (double)f; }
@@ -77,7 +77,7 @@ MRCHIP_EXPORT int mrchip_selftest_optimise_quotients(mrchip_ctx *ctx, long long 
     TRY(bad.alloc(ctx, 256));
     TRY(optimise_div_selftest(ctx, s, bad.as<unsigned long long>()));
     unsigned long long h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, &h, bad.p, 8));
     HIP_TRY(hipStreamSynchronize(s));
     *mismatches = (long long)h;
     return 0;
@@ -194,7 +194,7 @@ MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int
     HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
     TRY(launch_estimate_sigma_jobs(ctx, s, &job, jb.as<SigJob>(), 1, kind, res.as<double>()));
-    HIP_TRY(hipMemcpyAsync(sigma, res.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, sigma, res.p, sizeof(double)));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
@@ -205,6 +205,80 @@ MRCHIP_EXPORT int mrchip_estimate_noise_u8(mrchip_ctx *ctx, const uint8_t *gray,
     int ws = (int)(w / 2.0 - w / 4.0), we = (int)(w / 2.0 + w / 4.0);
     if (he == 0 || we == 0) { hs = 0; he = h; ws = 0; we = w; }           // mrc.py:288-292
     return mrchip_estimate_sigma(ctx, gray + (size_t)hs * w + ws, w, we - ws, he - hs, 0, sigma);
+}
+
+// ---- the same two stages on a float32 image that does not hold whole numbers 0..255 (mrc.py:273-329 take any float32
+// image; the production path, mrc.py:372, always passes float32(gray) and uses the uint8 entry points above) -------------
+MRCHIP_EXPORT int mrchip_estimate_sigma_f32(mrchip_ctx *ctx, const float *arr, int stride, int w, int h, double *sigma) {
+    CHECK_CTX(ctx);
+    if (!arr || !sigma || w <= 0 || h <= 0 || stride < w) { set_error("estimate_sigma_f32: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    DevBuf plane, scratch, res, jb;
+    const int pitch = round_up(w * 4 + 64, 64);                  // bytes
+    TRY(plane.alloc(ctx, (size_t)pitch * h + 2 * PAD));
+    TRY(scratch.alloc(ctx, sigma_scratch_bytes(w, h, 2)));
+    TRY(res.alloc(ctx, 64));
+    TRY(jb.alloc(ctx, sizeof(SigJob)));
+    uint8_t *p0 = plane.as<uint8_t>() + PAD;
+    TRY(upload_2d(s, p0, pitch, reinterpret_cast<const uint8_t *>(arr), stride * 4, w * 4, h));
+    SigJob job = {p0, pitch, w, h, 0, scratch.as<char>()};
+    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
+    TRY(launch_estimate_sigma_jobs(ctx, s, &job, jb.as<SigJob>(), 1, 2, res.as<double>()));
+    TRY(download_1d(s, sigma, res.p, sizeof(double)));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_estimate_noise_f32(mrchip_ctx *ctx, const float *gray, int w, int h, double *sigma) {
+    if (!gray || w <= 0 || h <= 0) { set_error("estimate_noise_f32: bad arguments"); return MRCHIP_E_ARG; }
+    int hs = (int)(h / 2.0 - h / 4.0), he = (int)(h / 2.0 + h / 4.0);      // mrc.py:282-285
+    int ws = (int)(w / 2.0 - w / 4.0), we = (int)(w / 2.0 + w / 4.0);
+    if (he == 0 || we == 0) { hs = 0; he = h; ws = 0; we = w; }           // mrc.py:288-292
+    return mrchip_estimate_sigma_f32(ctx, gray + (size_t)hs * w + ws, w, we - ws, he - hs, sigma);
+}
+
+MRCHIP_EXPORT int mrchip_gaussian_f32(mrchip_ctx *ctx, const float *in, uint8_t *out, int w, int h, double sigma,
+                                      const double *weights, int radius) {
+    CHECK_CTX(ctx);
+    if (!in || !out || w <= 0 || h <= 0) { set_error("gaussian_f32: bad arguments"); return MRCHIP_E_ARG; }
+    std::vector<double> wl;
+    if (radius == 0 && !weights) {
+        wl.assign(1, 1.0);                    // no blur: out = uint8(in), the astype of mrc.py:325 alone
+        weights = wl.data();
+    } else if (!weights) {
+        if (!(sigma > 0)) { set_error("gaussian_f32: sigma must be positive"); return MRCHIP_E_ARG; }
+        TRY(gaussian_weights_libm(sigma, wl));
+        weights = wl.data();
+        radius = (int)(wl.size() / 2);
+    } else if (radius != (int)(4.0 * sigma + 0.5)) {
+        set_error("gaussian_f32: radius %d does not match sigma %.17g (scipy: int(4*sigma+0.5))", radius, sigma);
+        return MRCHIP_E_ARG;
+    }
+    if (radius < 0 || radius > GMAXR) { set_error("gaussian_f32: radius %d outside [0,%d]", radius, GMAXR); return MRCHIP_E_UNSUPPORTED; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    DevBuf src, tmp, gw;
+    Img8 dst;
+    const int fp = round_up(w + 16, 16);                         // floats per row
+    TRY(src.alloc(ctx, (size_t)fp * h * sizeof(float)));
+    TRY(tmp.alloc(ctx, (size_t)fp * h * sizeof(float)));
+    TRY(dst.alloc(ctx, w, h));
+    TRY(gw.alloc(ctx, sizeof(GaussW)));
+    GaussW G;
+    memset(&G, 0, sizeof(G));
+    G.radius = radius;
+    for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
+    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    TRY(upload_2d(s, src.as<uint8_t>(), fp * 4, reinterpret_cast<const uint8_t *>(in), w * 4, w * 4, h));
+    HIP_TRY(hipStreamSynchronize(s));      // G lives on this stack frame
+    Plane pd;
+    pd.p = dst.p; pd.pitch = dst.pitch;
+    TRY(launch_gaussian_f32(ctx, s, src.as<float>(), fp, pd, w, h, gw.as<GaussW>(), tmp.as<float>(), fp));
+    TRY(download_2d(s, out, w, dst.p, dst.pitch, w, h));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
 }
 
 MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *out, int w, int h, double sigma,
@@ -236,12 +310,13 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
     memset(&G, 0, sizeof(G));
     G.radius = radius;
     for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
+    const bool fast_ok = gauss_weights_allow_fast(G);
     if (gauss_uses_fused(w, h, radius)) gauss_pad_weights(G, radius);
     HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     Plane pa, pb;
     pa.p = a.p; pa.pitch = a.pitch; pb.p = b.p; pb.pitch = b.pitch;
-    TRY(launch_gaussian_batch(ctx, s, pa, pb, w, h, gw.as<GaussW>(), tmp.as<float>(), tp, 0, 1, radius));
+    TRY(launch_gaussian_batch(ctx, s, pa, pb, w, h, gw.as<GaussW>(), tmp.as<float>(), tp, 0, 1, radius, fast_ok));
     TRY(download_2d(s, out, w, b.p, b.pitch, w, h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -287,7 +362,57 @@ MRCHIP_EXPORT int mrchip_thumbnail_ex(mrchip_ctx *ctx, const uint8_t *in, int w,
     p1.p = s1.as<uint8_t>(); p1.pitch = p.rw * c;
     p2.p = s2.as<uint8_t>(); p2.pitch = s2w;
     TRY(launch_thumbnail_plan(ctx, s, p, psrc, pdst, tab.p, p1, p2, 1));
-    HIP_TRY(hipMemcpyAsync(out, dst.p, (size_t)p.ow * p.oh * c, hipMemcpyDeviceToHost, s));
+    TRY(download_1d(s, out, dst.p, (size_t)p.ow * p.oh * c));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- internetarchivepdf/grayconvert.py:38-66 special_gray_convert (recode.py:362) ---------------------------------------
+// Two calls because the reference's scalar arithmetic between the two passes (bright_adjust, the thresholds, the level
+// tables) is host work in the host's numpy: `begin` uploads the page, leaves it on the device and returns the exact
+// channel statistics; `finish` takes the tables the host derived from them and produces the gray page.
+MRCHIP_EXPORT int mrchip_special_gray_begin(mrchip_ctx *ctx, const uint8_t *rgb, int w, int h, unsigned long long *stats) {
+    CHECK_CTX(ctx);
+    if (!rgb || !stats || w <= 0 || h <= 0) { set_error("special_gray_begin: bad arguments"); return MRCHIP_E_ARG; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    delete ctx->gray_pending;
+    ctx->gray_pending = nullptr;
+    GrayPending *g = new GrayPending;
+    struct Guard { GrayPending *g; ~Guard() { delete g; } } guard{g};       // released on every early return
+    TRY(g->src.alloc(ctx, w, h, 3));
+    g->w = w; g->h = h;
+    DevBuf st;
+    TRY(st.alloc(ctx, 256));
+    TRY(upload_2d(s, g->src.p, g->src.pitch, rgb, w * 3, w * 3, h));
+    TRY(launch_rgb_stats(ctx, s, g->src.p, g->src.pitch, w, h, st.p));
+    RgbStats hs;
+    TRY(download_1d(s, &hs, st.p, sizeof(hs)));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int c = 0; c < 3; c++) {
+        stats[c] = hs.mn[c]; stats[3 + c] = hs.mx[c]; stats[6 + c] = hs.sum[c]; stats[9 + c] = hs.sumsq[c];
+    }
+    ctx->gray_pending = g;
+    guard.g = nullptr;
+    return 0;
+}
+
+MRCHIP_EXPORT int mrchip_special_gray_finish(mrchip_ctx *ctx, const uint8_t *level_luts, const uint8_t *hsl_table, uint8_t *out) {
+    CHECK_CTX(ctx);
+    GrayPending *g = ctx->gray_pending;
+    if (!g) { set_error("special_gray_finish: no page pending (mrchip_special_gray_begin first)"); return MRCHIP_E_STATE; }
+    hipStream_t s = ctx->streams[0];
+    ScratchSync scratch_guard(ctx, s);
+    struct Guard { mrchip_ctx *c; ~Guard() { delete c->gray_pending; c->gray_pending = nullptr; } } guard{ctx};   // the page is consumed
+    if (!level_luts || !hsl_table || !out) { set_error("special_gray_finish: bad arguments"); return MRCHIP_E_ARG; }
+    Img8 dst;
+    DevBuf tab;
+    TRY(dst.alloc(ctx, g->w, g->h));
+    TRY(tab.alloc(ctx, 3 * 256 + 256 * 256));
+    HIP_TRY(hipMemcpyAsync(tab.p, level_luts, 3 * 256, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tab.as<uint8_t>() + 3 * 256, hsl_table, 256 * 256, hipMemcpyHostToDevice, s));
+    TRY(launch_rgb_level_hsl(ctx, s, g->src.p, g->src.pitch, dst.p, dst.pitch, g->w, g->h, tab.as<uint8_t>()));
+    TRY(download_2d(s, out, g->w, dst.p, dst.pitch, g->w, g->h));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }

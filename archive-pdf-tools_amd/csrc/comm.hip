@@ -126,7 +126,7 @@ MRCHIP_EXPORT int mrchip_comm_bcast(mrchip_comm *c, void *buf, size_t bytes, int
     TRY(comm_stage(c, bytes));
     if (c->rank == root) HIP_TRY(hipMemcpyAsync(c->dbuf, buf, bytes, hipMemcpyHostToDevice, c->s));
     NCCL_TRY(c, rccl()->bcast(c->dbuf, c->dbuf, bytes, kUint8, root, c->comm, c->s));
-    HIP_TRY(hipMemcpyAsync(buf, c->dbuf, bytes, hipMemcpyDeviceToHost, c->s));
+    TRY(download_1d(c->s, buf, c->dbuf, bytes));
     HIP_TRY(hipStreamSynchronize(c->s));
     return 0;
 }
@@ -140,7 +140,7 @@ MRCHIP_EXPORT int mrchip_comm_allgather(mrchip_comm *c, const void *send, size_t
     unsigned char *d = static_cast<unsigned char *>(c->dbuf);
     HIP_TRY(hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, c->s));
     NCCL_TRY(c, rccl()->allgather(d, d + bytes, bytes, kUint8, c->comm, c->s));
-    HIP_TRY(hipMemcpyAsync(recv, d + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->s));
+    TRY(download_1d(c->s, recv, d + bytes, bytes * (size_t)c->world));
     HIP_TRY(hipStreamSynchronize(c->s));
     return 0;
 }
@@ -152,7 +152,7 @@ MRCHIP_EXPORT int mrchip_comm_allreduce_f64(mrchip_comm *c, double *vals, int n,
     TRY(comm_stage(c, (size_t)n * 8));
     HIP_TRY(hipMemcpyAsync(c->dbuf, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->s));
     NCCL_TRY(c, rccl()->allreduce(c->dbuf, c->dbuf, (size_t)n, kFloat64, op == 1 ? kMax : kSum, c->comm, c->s));
-    HIP_TRY(hipMemcpyAsync(vals, c->dbuf, (size_t)n * 8, hipMemcpyDeviceToHost, c->s));
+    TRY(download_1d(c->s, vals, c->dbuf, (size_t)n * 8));
     HIP_TRY(hipStreamSynchronize(c->s));
     return 0;
 }

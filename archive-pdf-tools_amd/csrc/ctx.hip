@@ -64,6 +64,17 @@ long long canary_check_all(mrchip_ctx *ctx) {
     return bad;
 }
 
+// MRCHIP_POISON=1 (debugging switch, default off): every block is filled with 0xDD each time the allocator hands it out
+// -- a byte of an output that is still 0xDD after the call was never written on the device (no kernel store reached it, or
+// the download ran before the kernel had), where stale contents of the block's previous use would pass for data.
+static int poison_block(void *p, size_t bytes) {
+    static const bool on = getenv("MRCHIP_POISON") && atoi(getenv("MRCHIP_POISON")) != 0;
+    if (!on) return 0;
+    HIP_TRY(hipMemset(p, 0xDD, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     const size_t guard = canary_bytes();
     bytes = ((std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095) + 2 * guard;     // never a zero-byte (null) block
@@ -76,7 +87,7 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     if (best >= 0) {
         ctx->blocks[best].busy = true;
         *out = (char *)ctx->blocks[best].base + guard;
-        return 0;
+        return poison_block(*out, ctx->blocks[best].bytes - 2 * guard);
     }
     void *p = nullptr;
     auto drop_cache = [&]() {
@@ -127,7 +138,7 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     b.base = p; b.bytes = bytes; b.busy = true; b.guard = guard;
     ctx->blocks.push_back(b);
     *out = (char *)p + guard;
-    return 0;
+    return poison_block(*out, bytes - 2 * guard);
 }
 
 // Returned blocks stay cached for reuse (hipMalloc / hipFree synchronise the device); the cache is trimmed,
@@ -164,8 +175,42 @@ int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int s
     return 0;
 }
 
+// ---- downloads into ordinary (pageable) host memory ------------------------------------------------------------
+// Round 6, tests/fuzz_parity.py with 36 processes on one GPU: three host-buffer calls on large inputs (two Sauvola, one
+// thumbnail; profiles/r06_fuzz_runs.txt) returned outputs of which a part -- the bytes the kernel stores LAST: the tail of
+// the thumbnail, one wave's piece of a row -- held the block's old contents: the device-to-host copy enqueued on the
+// stream behind the kernel had read the buffer before the kernel had finished writing it.  The copies in question are
+// `hipMemcpy(2D)Async` into pageable memory, which the runtime does not execute as one ordered DMA command (it stages
+// or pins behind the scenes).  So a download whose destination is not page-locked is no longer handed to the runtime
+// while anything is pending on the stream: the stream is drained first.  Destinations in page-locked memory
+// (mrchip_host_alloc: the streaming pipeline) are true stream-ordered DMAs and stay asynchronous.
+// MRCHIP_DOWNLOAD_ORDER=0 restores the old behaviour (the A/B switch of tests/stress_copy_order.py).
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                   // unregistered host memory: the query fails, the error state is cleared
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int order_before_download(hipStream_t s, const void *host_dst) {
+    const char *e = getenv("MRCHIP_DOWNLOAD_ORDER");          // (read per call: the stress test runs both forms)
+    if (e && atoi(e) == 0) return 0;
+    if (!host_is_pinned(host_dst)) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
+    TRY(order_before_download(s, dst));
     HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
+    TRY(order_before_download(s, dst));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
     return 0;
 }
 
@@ -282,6 +327,8 @@ MRCHIP_EXPORT void mrchip_destroy(mrchip_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx->host_mail;                 // (before the blocks go: its DevBufs return to the allocator first)
     ctx->host_mail = nullptr;
+    delete ctx->gray_pending;
+    ctx->gray_pending = nullptr;
     for (auto &b : ctx->blocks)
         if (b.base) (void)hipFree(b.base);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -450,7 +450,7 @@ int launch_denoise_batch(mrchip_ctx *ctx, hipStream_t s, Plane mask, int w, int 
                                   flag.as<int>()));
         uint8_t *t = cur; cur = nxt; nxt = t;
         int changed = 0;
-        HIP_TRY(hipMemcpyAsync(&changed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        TRY(download_1d(s, &changed, flag.p, sizeof(int)));
         HIP_TRY(hipStreamSynchronize(s));
         if (!changed) break;
     }

@@ -54,6 +54,21 @@ __global__ __launch_bounds__(256) void gauss_v_kernel(const uint8_t *src, int sp
     *reinterpret_cast<float4 *>(tmp + (size_t)y * tpitch + x) = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
 
+// vertical pass over a float32 source (round 6: mrc.create_threshold_mask on a float32 image that does not hold whole
+// numbers 0..255): scipy's line buffer is double, so the pair sum is a rounded float64 addition like every other step
+__global__ __launch_bounds__(256) void gauss_v_f32_kernel(const float *src, int spitch, float *tmp, int tpitch, int w, int h,
+                                                          const GaussW *Gs) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const GaussW &G = Gs[0];
+    const int r = G.radius;
+    double acc = __dmul_rn((double)src[(size_t)y * spitch + x], G.w[r]);
+    for (int j = -r; j < 0; j++)
+        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)src[(size_t)reflect_idx(y + j, h) * spitch + x],
+                                                  (double)src[(size_t)reflect_idx(y - j, h) * spitch + x]), G.w[r + j]));
+    tmp[(size_t)y * tpitch + x] = (float)acc;
+}
+
 // horizontal pass: one lane per output (consecutive lanes read consecutive floats)
 __global__ __launch_bounds__(256) void gauss_h_kernel(const float *tmp, int tpitch, size_t tstride, uint8_t *dst,
                                                       int dpitch, size_t dstride, int w, int h, const GaussW *Gs) {
@@ -510,19 +525,23 @@ __global__ __launch_bounds__(256) void gauss_fix_kernel(const uint8_t *src, int 
 }
 
 // the marked tiles with the float64 tile code: every workgroup scans its share of the count words (normally none is marked)
+constexpr unsigned GQ_REDO_CHUNK = 32;
 template <int R>
 __global__ __launch_bounds__(GF_THREADS) void gauss_exact_tiles_kernel(const uint8_t *src, int spitch, size_t sstride,
                                                                        uint8_t *dst, int dpitch, size_t dstride, int w, int h,
                                                                        const GaussW *Gs, const unsigned *tcnt, unsigned ntiles,
                                                                        int gx, int gy) {
     __shared__ __attribute__((aligned(16))) float tmpT[GF_TH][GF_LW];
-    __shared__ unsigned marked[GF_THREADS];
+    // GQ_REDO_CHUNK count words per workgroup and round: marked tiles come in runs (a flat margin is a block of them), and
+    // a workgroup redoes the ones it found one after the other -- with 256 words per round and one workgroup per CU
+    // (round 5) a page with clipped-white margins left most CUs idle behind a few long queues
+    __shared__ unsigned marked[GQ_REDO_CHUNK];
     __shared__ unsigned nmarked;
-    for (unsigned base = blockIdx.x * GF_THREADS; base < ntiles; base += gridDim.x * GF_THREADS) {
+    for (unsigned base = blockIdx.x * GQ_REDO_CHUNK; base < ntiles; base += gridDim.x * GQ_REDO_CHUNK) {
         if (threadIdx.x == 0) nmarked = 0;
         __syncthreads();
         const unsigned t = base + threadIdx.x;
-        if (t < ntiles && tcnt[t] == 0xffffffffu) marked[atomicAdd(&nmarked, 1u)] = t;
+        if (threadIdx.x < GQ_REDO_CHUNK && t < ntiles && tcnt[t] == 0xffffffffu) marked[atomicAdd(&nmarked, 1u)] = t;
         __syncthreads();
         const unsigned nm = nmarked;
         for (unsigned i = 0; i < nm; i++) {
@@ -637,8 +656,32 @@ int gaussian_weights_libm(double sigma, std::vector<double> &wts) {
 
 // radius 0 (weight 1.0) is the identity: float32(u8) -> u8, so pages without blur (sigma_est <= 1,
 // mrc.py:309) ride along in the same launch.
+// The float32 form's undecided band E(R) is derived for tables whose taps are non-negative and add up to 1: every
+// partial sum then stays below 256 and half an ulp of it is 2^-17.  A caller-supplied table that is not like that (the
+// entry points take any) must not go through it: wrong bytes would come out silently.
+// float32 image in (pitch in floats), uint8 out = trunc(float32 result): the two streaming passes (radius 0: a copy + trunc)
+int launch_gaussian_f32(mrchip_ctx *ctx, hipStream_t s, const float *src, int spitch, Plane dst, int w, int h,
+                        const GaussW *d_weights, float *tmp, int tpitch) {
+    dim3 grid(cdiv(w, 256), h, 1);
+    LAUNCH(ctx, s, "gauss_v_f32", 8.0 * w * h,
+           hipLaunchKernelGGL(gauss_v_f32_kernel, grid, dim3(256), 0, s, src, spitch, tmp, tpitch, w, h, d_weights));
+    LAUNCH(ctx, s, "gauss_h", 5.0 * w * h,
+           hipLaunchKernelGGL(gauss_h_kernel, grid, dim3(256), 0, s, tmp, tpitch, (size_t)0, dst.p, dst.pitch, dst.stride, w, h,
+                              d_weights));
+    return 0;
+}
+
+bool gauss_weights_allow_fast(const GaussW &g) {
+    double sum = 0;
+    for (int i = 0; i < 2 * g.radius + 1; i++) {
+        if (!(g.w[i] >= 0.0)) return false;
+        sum += g.w[i];
+    }
+    return sum >= 1.0 - 1e-9 && sum <= 1.0 + 1e-9;
+}
+
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
-                          float *tmp, int tpitch, size_t tstride, int npages, int max_radius) {
+                          float *tmp, int tpitch, size_t tstride, int npages, int max_radius, bool fast_ok) {
     if (max_radius >= 1 && max_radius <= GF_RMAX && w >= 2 * GF_RMAX && h >= 2 * GF_RMAX) {
         // d_weights must be padded to max_radius (gauss_pad_weights)
         dim3 gridf(cdiv(w, GF_TW), cdiv(h, GF_TH), npages);
@@ -648,7 +691,7 @@ int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, 
         const size_t ntiles = (size_t)gridf.x * gridf.y * gridf.z;
         const size_t tmp_bytes = (npages > 1 ? tstride * (size_t)npages : (size_t)tpitch * h) * sizeof(float);
         const size_t need = ntiles * ((size_t)GQ_CAP + 1) * 4;
-        if (!(fast_env && atoi(fast_env) == 0) && tmp && need <= tmp_bytes && ntiles < (1u << 31)) {
+        if (fast_ok && !(fast_env && atoi(fast_env) == 0) && tmp && need <= tmp_bytes && ntiles < (1u << 31)) {
             unsigned *tcnt = reinterpret_cast<unsigned *>(tmp);                 // one count word per tile, written by every tile
             unsigned *tslots = tcnt + ntiles;                                   // GQ_CAP slots per tile
             const int cus = ctx->cus > 0 ? ctx->cus : 256;
@@ -663,7 +706,7 @@ int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, 
                hipLaunchKernelGGL(gauss_fix_kernel<RR>, dim3(std::min<size_t>((ntiles + 255) / 256, (size_t)cus * 8)), dim3(256), 0, s, src.p, src.pitch, src.stride, dst.p, \
                                   dst.pitch, dst.stride, w, h, d_weights, tcnt, tslots, (unsigned)ntiles, gx, gy)); \
         LAUNCH(ctx, s, "gauss_redo", 0.0,                                                                         \
-               hipLaunchKernelGGL(gauss_exact_tiles_kernel<RR>, dim3(cus), dim3(GF_THREADS), 0, s, src.p, src.pitch, \
+               hipLaunchKernelGGL(gauss_exact_tiles_kernel<RR>, dim3((unsigned)std::min<size_t>((ntiles + GQ_REDO_CHUNK - 1) / GQ_REDO_CHUNK, (size_t)cus * 8)), dim3(GF_THREADS), 0, s, src.p, src.pitch, \
                                   src.stride, dst.p, dst.pitch, dst.stride, w, h, d_weights, tcnt, (unsigned)ntiles, gx, gy)); \
         break;
             switch (max_radius) { GQ_CASE(1) GQ_CASE(2) GQ_CASE(3) GQ_CASE(4) GQ_CASE(5) GQ_CASE(6) GQ_CASE(7) GQ_CASE(8) }

@@ -821,9 +821,9 @@ static const SauvolaTable *decision_table(mrchip_ctx *ctx, double k, double R) {
                 hipMalloc((void **)&d_full, 65536 * 2) == hipSuccess;
     if (good) {
         hipLaunchKernelGGL(sauvola_t2_build_kernel, dim3(256), dim3(256), 0, st, d_full, k - 1, k * k / R / R);   // pyx:62
-        good = hipGetLastError() == hipSuccess &&
-               hipMemcpyAsync(full.data(), d_full, 65536 * 2, hipMemcpyDeviceToHost, st) == hipSuccess &&
-               hipStreamSynchronize(st) == hipSuccess;
+        // (the kernel is waited for BEFORE the copy into pageable memory is handed to the runtime: ctx.hip, download_1d)
+        good = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+               hipMemcpy(full.data(), d_full, 65536 * 2, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (d_full) (void)hipFree(d_full);
     if (st) (void)hipStreamDestroy(st);

@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256) void sel_reset_kernel(const SigJob *jobs) {
 // (axis 0: ((0 + f0*x[i]) + f1*x[i-1]) + ..., then axis 1 likewise); coefficients whose taps leave
 // the array take PyWavelets' symmetric-extension order in dwt_point.  DWT_RPB rows per workgroup
 // share one LDS histogram.
+// F32SRC (round 6): the source is a float32 image (`pitch` still in bytes) -- mrc.estimate_noise on a float32 array that
+// does not hold whole numbers 0..255 (mrc.py:273-296 takes any).  Every coefficient then goes through dwt_point, the
+// one-output form in PyWavelets' own order; rare and small, so no fast path.
 constexpr int DWT_RPB = 4;
-template <class T>
+template <class T, bool F32SRC = false>
 __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> F, size_t dd_off) {
     const SigJob J = jobs[blockIdx.z];
     const int w = J.w, h = J.h, pitch = J.pitch;
@@ -109,12 +112,15 @@ __global__ __launch_bounds__(256) void dwt_dd_kernel(const SigJob *jobs, Db2<T> 
     const uint8_t *src = J.src;
     T *dd = reinterpret_cast<T *>(J.scratch + dd_off);
     auto cv = [&](unsigned v) -> T { return AS_BOOL ? (T)(v ? 1 : 0) : (T)v; };
-    auto px = [&](int yy, int xx) -> T { return cv(src[(size_t)yy * pitch + xx]); };
+    auto px = [&](int yy, int xx) -> T {
+        if constexpr (F32SRC) return (T) * reinterpret_cast<const float *>(src + (size_t)yy * pitch + (size_t)xx * 4);
+        else return cv(src[(size_t)yy * pitch + xx]);
+    };
     // The symmetric extension on the left / top is an index reflection with the taps still in
     // ascending filter order, and so is the right / bottom one as long as at most two taps overhang
     // (the two swapped products commute); three overhang only for the last coefficient of an odd
     // length, which keeps PyWavelets' order in dwt_point.  Tiny arrays go there entirely.
-    const bool roomy = w >= 8 && h >= 4;
+    const bool roomy = !F32SRC && w >= 8 && h >= 4;
     for (int rr = 0; rr < DWT_RPB; rr++) {
         const int k = blockIdx.y * DWT_RPB + rr;            // row of dd
         if (k >= h2 || m0 >= w2) break;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(64) void sel_scan_kernel(const SigJob *jobs, int bi
 
 static size_t dd_offset() { return (sizeof(SelState) + 255) & ~(size_t)255; }
 
-template <class T>
+template <class T, bool F32SRC = false>
 static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
                      double *d_sigma) {
     static const double HI[4] = {-0.48296291314453416, 0.8365163037378079, -0.2241438680420134,
@@ -321,7 +327,7 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const
     }
     LAUNCH(ctx, s, "median_reset", 0.0, hipLaunchKernelGGL(sel_reset_kernel, dim3(njobs), dim3(256), 0, s, d_jobs));
     LAUNCH(ctx, s, sizeof(T) == 4 ? "dwt_dd_f32" : "dwt_dd_f64", alg,
-           hipLaunchKernelGGL((dwt_dd_kernel<T>), dim3(cdiv(maxw2, 1024), cdiv(maxh2, DWT_RPB), njobs), dim3(256), 0, s,
+           hipLaunchKernelGGL((dwt_dd_kernel<T, F32SRC>), dim3(cdiv(maxw2, 1024), cdiv(maxh2, DWT_RPB), njobs), dim3(256), 0, s,
                               d_jobs, F, dd_offset()));
     const int blocks = (int)std::min<size_t>(njobs > 8 ? 64 : 512, (maxn + 255) / 256);
     int shift = Key<T>::BITS;
@@ -343,7 +349,7 @@ static int run_sigma(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const
 
 size_t sigma_scratch_bytes(int w, int h, int kind) {
     const size_t n = (size_t)((w + 3) / 2) * ((h + 3) / 2);
-    return ((dd_offset() + n * (kind ? sizeof(double) : sizeof(float)) + 255) & ~(size_t)255);
+    return ((dd_offset() + n * (kind == 1 ? sizeof(double) : sizeof(float)) + 255) & ~(size_t)255);
 }
 
 // h_jobs / d_jobs: the same njobs records on host and device; job i's result lands in d_sigma[i]
@@ -358,6 +364,7 @@ int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_j
     for (int i = 0; i < njobs; i++)
         if (h_jobs[i].w <= 0 || h_jobs[i].h <= 0) { set_error("estimate_sigma: empty array"); return MRCHIP_E_ARG; }
     if (kind == 0) return run_sigma<float>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);
+    if (kind == 2) return run_sigma<float, true>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);      // float32 source plane
     return run_sigma<double>(ctx, s, h_jobs, d_jobs, njobs, d_sigma);
 }
 

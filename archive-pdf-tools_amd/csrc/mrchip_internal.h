@@ -75,6 +75,7 @@ struct ProfPending {
 };
 
 struct OptMail;
+struct GrayPending;
 constexpr int NSTREAMS = 4;
 constexpr int MAX_GRID_Z = 65535;      // hipDeviceProp_t::maxGridSize[2] (and [1])
 
@@ -99,6 +100,8 @@ struct mrchip_ctx {
     // hand-off buffers / error word of mrchip_optimise's launches (one per context: a per-call object would allocate and free
     // page-locked memory -- two device synchronisations -- on every call)
     mrchip::OptMail *host_mail = nullptr;
+    // the page mrchip_special_gray_begin left on the device for mrchip_special_gray_finish
+    mrchip::GrayPending *gray_pending = nullptr;
     int cus = 0;
     size_t hbm = 0;
     char name[128] = {};
@@ -161,8 +164,27 @@ struct Img8 {
     size_t bytes() const { return (size_t)pitch * h; }
 };
 
+// grayconvert.py: the RGB page between the statistics pass and the table pass (it crosses PCIe once)
+struct GrayPending {
+    Img8 src;
+    int w = 0, h = 0;
+};
+struct RgbStats {                     // what the statistics kernel leaves for the host (80 bytes)
+    unsigned mn[3], mx[3];
+    unsigned pad_[2];
+    unsigned long long sum[3], sumsq[3];
+};
+// d_stats: one RgbStats
+int launch_rgb_stats(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int pitch, int w, int h, void *d_stats);
+// d_tables: 3 * 256 bytes of per-channel level tables, then 256 * 256 bytes indexed max * 256 + min
+int launch_rgb_level_hsl(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int rgb_pitch, uint8_t *gray, int gray_pitch, int w,
+                         int h, const uint8_t *d_tables);
+
 int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
 int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
+// linear device-to-host copy of pixel data; like download_2d it drains the stream first when `dst` is pageable (ctx.hip)
+int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
+int order_before_download(hipStream_t s, const void *host_dst);
 
 // profiling hooks: prof_begin returns a token (<0: disabled)
 int prof_begin(mrchip_ctx *ctx, hipStream_t s, const char *name, double alg_bytes);
@@ -323,7 +345,7 @@ size_t sigma_scratch_bytes(int w, int h, int kind);
 struct SigJob {
     const uint8_t *src; int pitch;
     int w, h;
-    int as_bool;
+    int as_bool;        // (the launch's `kind` decides how src is read: 0 uint8 as float32, 1 bool as float64, 2 float32 plane)
     char *scratch;      // sigma_scratch_bytes(w, h, kind) bytes, 256-byte aligned
 };
 int launch_estimate_sigma_jobs(mrchip_ctx *ctx, hipStream_t s, const SigJob *h_jobs, const SigJob *d_jobs, int njobs,
@@ -336,8 +358,12 @@ int gauss_fast_selftest(mrchip_ctx *ctx, hipStream_t s, const GaussW *d_w, unsig
 void gauss_pad_weights(GaussW &g, int R);
 // max_radius: the largest radius among the pages (host knows it): <= 8 takes the fused LDS kernel,
 // which expects every page's table padded to max_radius (gauss_pad_weights)
+int launch_gaussian_f32(mrchip_ctx *ctx, hipStream_t s, const float *src, int spitch, Plane dst, int w, int h,
+                        const GaussW *d_weights, float *tmp, int tpitch);
+// fast_ok: every page's table passed gauss_weights_allow_fast (before padding), so the float32 form may be taken
+bool gauss_weights_allow_fast(const GaussW &g);
 int launch_gaussian_batch(mrchip_ctx *ctx, hipStream_t s, Plane src, Plane dst, int w, int h, const GaussW *d_weights,
-                          float *tmp, int tpitch, size_t tstride, int npages, int max_radius);
+                          float *tmp, int tpitch, size_t tstride, int npages, int max_radius, bool fast_ok = true);
 // bits: page i at bits + i*bits_stride dwords
 // want_rowflags: also leave one byte per row ("the finished row has a set pixel") at denoise_rowflags_offset(w, h) of
 // each page's scratch (n = 2, mincnt = 4 path only)

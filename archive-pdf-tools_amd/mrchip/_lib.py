@@ -16,6 +16,7 @@ MAX_TAPS = 128        # MRCHIP_MAX_TAPS
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
 intp = C.POINTER(C.c_int)
 vp = C.c_void_p
 
@@ -98,6 +99,11 @@ SIGNATURES = {
     'mrchip_comm_bcast': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_int]),
     'mrchip_comm_allgather': (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mrchip_comm_allreduce_f64': (C.c_int, [vp, f64p, C.c_int, C.c_int]),
+    'mrchip_estimate_sigma_f32': (C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f64p]),
+    'mrchip_estimate_noise_f32': (C.c_int, [vp, f32p, C.c_int, C.c_int, f64p]),
+    'mrchip_gaussian_f32': (C.c_int, [vp, f32p, u8p, C.c_int, C.c_int, C.c_double, f64p, C.c_int]),
+    'mrchip_special_gray_begin': (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
+    'mrchip_special_gray_finish': (C.c_int, [vp, u8p, u8p, u8p]),
     'mrchip_canary_check': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
     'mrchip_canary_selftest': (C.c_int, [vp, C.POINTER(C.c_longlong)]),
     'mrchip_prof_enable': (C.c_int, [vp, C.c_int]),

@@ -47,19 +47,27 @@ def threshold_image(img, dpi, k=0.34, ctx=None):
 
 
 def _u8_valued(imgf, what):
-    """The float32 images of this path are `np.array(grayimg, dtype=np.float32)` (mrc.py:372): whole numbers
-    0..255.  The device works on the uint8 plane; anything else is refused, never approximated."""
+    """The float32 images of the production path are `np.array(grayimg, dtype=np.float32)` (mrc.py:372): whole numbers
+    0..255, for which the device works on the uint8 plane (the fast kernels).  Returns (uint8 plane, None) for those and
+    (None, float32 array) for a float32 image with other values (round 6: the general form of mrc.py:273-329, slower
+    kernels, same results as the reference).  Other dtypes with non-uint8 values are refused: the reference would run
+    PyWavelets / scipy in float64 for them, which this path does not restate."""
     a = np.asarray(imgf)
     if a.ndim != 2:
         raise ValueError('%s: a 2-D image is expected, got shape %r' % (what, a.shape))
-    src = np.ascontiguousarray(a, dtype=np.uint8)
-    if a.dtype != np.uint8 and not np.array_equal(src, a):
-        raise _lib.MrchipError('%s: only images holding uint8 values (0..255, whole numbers) are supported' % what)
-    return src
+    if a.dtype == np.uint8:
+        return np.ascontiguousarray(a), None
+    with np.errstate(all='ignore'):
+        src = np.ascontiguousarray(a, dtype=np.uint8)
+    if np.array_equal(src, a):
+        return src, None
+    if a.dtype == np.float32:
+        return None, np.ascontiguousarray(a)
+    raise _lib.MrchipError('%s: a uint8-valued image or a float32 image is expected, got %s with other values' % (what, a.dtype))
 
 
 def mean_estimate_sigma(arr, ctx=None):
-    """mrc.mean_estimate_sigma (mrc.py:52-55) for float32 images holding uint8 values or bool arrays."""
+    """mrc.mean_estimate_sigma (mrc.py:52-55) for float32 images and bool arrays."""
     a = np.asarray(arr)
     ctx = ctx or _lib.default_context()
     sigma = C.c_double()
@@ -67,9 +75,12 @@ def mean_estimate_sigma(arr, ctx=None):
         src = np.ascontiguousarray(a).view(np.uint8)
         kind = 1
     else:
-        src = np.ascontiguousarray(a, dtype=np.uint8)
-        if not np.array_equal(src, a):
-            raise _lib.MrchipError('mean_estimate_sigma: only uint8-valued images and bool arrays are supported')
+        src, f32 = _u8_valued(a, 'mean_estimate_sigma')
+        if f32 is not None:
+            h, w = f32.shape
+            _lib.check(_lib.load().mrchip_estimate_sigma_f32(ctx.handle, _lib.ptr(f32, _lib.f32p), w, w, h, C.byref(sigma)),
+                       'mrchip_estimate_sigma_f32')
+            return sigma.value
         kind = 0
     h, w = src.shape
     _lib.check(_lib.load().mrchip_estimate_sigma(ctx.handle, _lib.ptr(src), w, w, h, kind, C.byref(sigma)),
@@ -78,11 +89,16 @@ def mean_estimate_sigma(arr, ctx=None):
 
 
 def estimate_noise(imgf, ctx=None):
-    """mrc.estimate_noise (mrc.py:273-296) on float32(gray)."""
-    src = _u8_valued(imgf, 'estimate_noise')
-    h, w = src.shape
+    """mrc.estimate_noise (mrc.py:273-296) on float32(gray) -- or on any float32 image (the general kernels)."""
+    src, f32 = _u8_valued(imgf, 'estimate_noise')
     ctx = ctx or _lib.default_context()
     sigma = C.c_double()
+    if f32 is not None:
+        h, w = f32.shape
+        _lib.check(_lib.load().mrchip_estimate_noise_f32(ctx.handle, _lib.ptr(f32, _lib.f32p), w, h, C.byref(sigma)),
+                   'mrchip_estimate_noise_f32')
+        return sigma.value
+    h, w = src.shape
     _lib.check(_lib.load().mrchip_estimate_noise_u8(ctx.handle, _lib.ptr(src), w, h, C.byref(sigma)),
                'mrchip_estimate_noise_u8')
     return sigma.value
@@ -162,16 +178,34 @@ def create_threshold_mask(mask_arr, imgf, dpi=None, denoise_mask=None, timing_da
     k=0.34 of the (truncated) result, OR-ed into mask_arr in place.  `imgf` is float32(gray) as in
     mrc.py:372; `denoise_mask` is accepted and unused like in the reference.  Timing keys est_1 / blur_1 /
     threshold as the reference appends them."""
-    gray = _u8_valued(imgf, 'create_threshold_mask')
+    gray, f32 = _u8_valued(imgf, 'create_threshold_mask')
     m = np.asarray(mask_arr)
-    if m.shape != gray.shape:
-        raise ValueError('create_threshold_mask: mask_arr shape %r does not match the image %r' % (m.shape, gray.shape))
+    if m.shape != (gray if f32 is None else f32).shape:
+        raise ValueError('create_threshold_mask: mask_arr shape %r does not match the image %r' % (m.shape, np.asarray(imgf).shape))
+    if f32 is not None and not (np.isfinite(f32).all() and f32.min() >= 0 and f32.max() < 256):
+        # imgf.astype(np.uint8) (mrc.py:325) of such values is what the C compiler of the reference's numpy makes of an
+        # out-of-range float -> uint8 cast: platform-defined, so there is nothing to be identical to
+        raise _lib.MrchipError('create_threshold_mask: float32 image values must be finite and in [0, 256)')
     ctx = ctx or _lib.default_context()
     t = time()
-    sigma_est = estimate_noise(gray, ctx=ctx)
+    sigma_est = estimate_noise(gray if f32 is None else f32, ctx=ctx)
     if timing_data is not None:
         timing_data.append(('est_1', time() - t))
-    if sigma_est > 1.0:                                                   # mrc.py:309-313
+    if f32 is not None:
+        # the general float32 form: scipy's float32 gaussian_filter (when sigma_est > 1) and the uint8 truncation, one call
+        t = time()
+        h, w = f32.shape
+        gray = np.empty((h, w), np.uint8)
+        if sigma_est > 1.0:                                               # mrc.py:309-313
+            wts, radius = gaussian_weights(sigma_est * 0.1)
+            _lib.check(_lib.load().mrchip_gaussian_f32(ctx.handle, _lib.ptr(f32, _lib.f32p), _lib.ptr(gray), w, h,
+                                                       float(sigma_est * 0.1), _lib.ptr(wts, _lib.f64p), radius), 'mrchip_gaussian_f32')
+            if timing_data is not None:
+                timing_data.append(('blur_1', time() - t))
+        else:
+            _lib.check(_lib.load().mrchip_gaussian_f32(ctx.handle, _lib.ptr(f32, _lib.f32p), _lib.ptr(gray), w, h, 0.0, None, 0),
+                       'mrchip_gaussian_f32')
+    elif sigma_est > 1.0:                                                 # mrc.py:309-313
         t = time()
         wts, radius = gaussian_weights(sigma_est * 0.1)
         h, w = gray.shape
@@ -192,15 +226,23 @@ def create_threshold_mask(mask_arr, imgf, dpi=None, denoise_mask=None, timing_da
         m |= thres_arr.view(np.uint8)
 
 
+def _require_skimage_for_bregman():
+    """denoise_mask='bregman' is a host pass through scikit-image, the dependency the reference itself uses for it
+    (mrc.py:34, 101).  Asked for where it is not installed, the call fails HERE -- when the option is given, before a
+    page is uploaded or a mask computed -- not minutes into a book."""
+    import importlib.util
+    if importlib.util.find_spec('skimage') is None:
+        raise ImportError("denoise_mask='bregman' needs scikit-image (skimage.restoration.denoise_tv_bregman), the same "
+                          "dependency the reference uses for it (mrc.py:34, 101); it is not installed in this environment. "
+                          "Use denoise_mask='fast' or 'none', or install scikit-image.")
+
+
 def denoise_bregman(binary_img):
     """mrc.denoise_bregman (mrc.py:90-108): host passthrough to scikit-image's iterative TV solver, which is
     third-party code the reference calls as is (SURVEY.md 8f rank 4 keeps it on the CPU).  Raises
     ImportError where scikit-image is not installed -- there is no stand-in."""
-    try:
-        from skimage.restoration import denoise_tv_bregman
-    except ImportError as e:
-        raise ImportError("denoise_mask='bregman' needs scikit-image (skimage.restoration.denoise_tv_bregman), "
-                          "the same dependency the reference uses for it (mrc.py:34, 101)") from e
+    _require_skimage_for_bregman()
+    from skimage.restoration import denoise_tv_bregman
     thresf = np.array(binary_img, dtype=np.float32)
     return np.array(denoise_tv_bregman(thresf, weight=1.) > 0.4, dtype=bool)
 
@@ -799,7 +841,17 @@ def create_mrc_hocr_components(image, hocr_word_data,
                                denoise_mask=None, timing_data=None,
                                errors=None, ctx=None):
     """mrc.create_mrc_hocr_components (mrc.py:334-471): generator yielding mask (bool[h,w]),
-    foreground and background (uint8 arrays), lazily, with the reference's timing keys."""
+    foreground and background (uint8 arrays), lazily, with the reference's timing keys.
+    One check runs when the function is CALLED rather than at the first next(): denoise_mask='bregman' without
+    scikit-image raises ImportError at once (every other argument error keeps the reference's timing)."""
+    if denoise_mask == DENOISE_BREGMAN:
+        _require_skimage_for_bregman()
+    return _mrc_hocr_components(image, hocr_word_data, dpi, downsample, bg_downsample, fg_downsample, denoise_mask,
+                                timing_data, errors, ctx)
+
+
+def _mrc_hocr_components(image, hocr_word_data, dpi, downsample, bg_downsample, fg_downsample, denoise_mask, timing_data,
+                         errors, ctx):
     image_arr, gray_arr = _image_to_array(image)
     height_, width_ = image_arr.shape[:2]
     channels = 1 if image_arr.ndim == 2 else 3

@@ -98,6 +98,18 @@ int mrchip_mask_denoise(mrchip_ctx *ctx, uint8_t *mask, int w, int h, int mincnt
 int mrchip_optimise(mrchip_ctx *ctx, const uint8_t *mask, const uint8_t *img, uint8_t *out,
                     int w, int h, int channels, int n_size, int invert_mask);
 
+/* ---- internetarchivepdf/grayconvert.py:38-66 special_gray_convert (recode.py:362) ----
+ * The reference computes per-channel min / max / mean / std (grayconvert.py:41-44), derives three level ranges from them
+ * in scalar Python (:46-54), applies level_arr per channel (:24-31, :56-60), converts with skimage.color.rgb2hsv and
+ * returns uint8(V (1 - S / 2) 255) (:62-66).  Here: `begin` uploads rgb uint8[h][w][3], keeps it on the device and returns
+ * stats[12] = {min r g b, max r g b, sum r g b, sum of squares r g b} as exact integers; the host side (mrchip/grayconvert.py)
+ * does the scalar arithmetic with the reference's own expressions and builds two byte tables -- level_luts[3][256]
+ * (level_arr of every byte value, per channel) and hsl_table[256][256] (the rgb2hsv + lightness result of a pixel as a
+ * function of its (max, min) after levelling, index max * 256 + min) -- which `finish` applies: out uint8[h][w].
+ * `finish` consumes the pending page (MRCHIP_E_STATE without one); a second `begin` replaces it. */
+int mrchip_special_gray_begin(mrchip_ctx *ctx, const uint8_t *rgb, int w, int h, unsigned long long *stats);
+int mrchip_special_gray_finish(mrchip_ctx *ctx, const uint8_t *level_luts, const uint8_t *hsl_table, uint8_t *out);
+
 /* ---- third-party stages reached from internetarchivepdf/mrc.py ----------- */
 /* PIL Image.convert('L') of an RGB image -- mrc.py:361. */
 int mrchip_luma601(mrchip_ctx *ctx, const uint8_t *rgb, uint8_t *gray, int w, int h);
@@ -116,6 +128,15 @@ int mrchip_estimate_noise_u8(mrchip_ctx *ctx, const uint8_t *gray, int w, int h,
  * the host (filters.py _gaussian_kernel1d); NULL = build it here with libm. */
 int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8_t *out, int w, int h,
                        double sigma, const double *weights, int radius);
+/* The same stages for a float32 image that does NOT hold whole numbers 0..255 (mrc.estimate_noise / create_threshold_mask,
+ * mrc.py:273-329, take any float32 array; the production path, mrc.py:372, passes float32(gray) and uses the uint8 entry
+ * points).  estimate_sigma_f32: `stride` in elements.  gaussian_f32: out = uint8(float32 result) -- scipy's float32
+ * gaussian_filter followed by the astype(np.uint8) of mrc.py:325 (truncation; the caller guarantees values in [0, 256),
+ * outside of which numpy's own cast is platform-defined); radius 0 with weights NULL = no blur, the cast alone. */
+int mrchip_estimate_sigma_f32(mrchip_ctx *ctx, const float *arr, int stride, int w, int h, double *sigma);
+int mrchip_estimate_noise_f32(mrchip_ctx *ctx, const float *gray, int w, int h, double *sigma);
+int mrchip_gaussian_f32(mrchip_ctx *ctx, const float *in, uint8_t *out, int w, int h, double sigma,
+                        const double *weights, int radius);
 
 /* PIL Image.thumbnail((req_w, req_h)) with defaults (BICUBIC, reducing_gap=2)
  * -- mrc.py:422-428, 456-462.  mrchip_thumbnail_size is the host-side size

@@ -368,3 +368,52 @@ def create_mrc_hocr_components(image, hocr_word_data, dpi=None, downsample=None,
         n = ow.value * oh.value * c
         res = out.reshape(-1)[:n].reshape((oh.value, ow.value) if c == 1 else (oh.value, ow.value, 3)).copy()
         yield res
+
+
+# ---- internetarchivepdf/grayconvert.py -----------------------------------------------------------
+def level_arr(arr, minv=0, maxv=255):
+    """grayconvert.py:24-31 on a uint8 array, in place: (arr - minv) / interval in float64, stored back into the uint8
+    array (C truncation), values below minv -> 0, above maxv -> 255."""
+    interval = (maxv / 255.) - (minv / 255.)
+    arr_zero = arr < minv
+    arr_max = arr > maxv
+    with np.errstate(all='ignore'):
+        arr[::] = ((arr[::] - minv) / interval)
+    arr[arr_zero] = 0
+    arr[arr_max] = 255
+    return arr
+
+
+def hsl_lightness_u8(rgb):
+    """What grayconvert.py:63-66 makes of a uint8 RGB image: skimage.color.rgb2hsv (0.18.3 colorconv.py:190-265) needs
+    only V = max and S = ptp / max of the image converted by img_as_float -- for uint8 input `np.multiply(image, 1 / 255,
+    dtype=float64)`: a multiplication by the reciprocal, not a division (util/dtype.py:312-320; the computation type is
+    the first of (float64, float32, float64) wider than the input) -- then l = V * (1 - S / 2) and uint8(l * 255) truncated."""
+    arr = np.multiply(rgb, 1. / 255, dtype=np.float64)
+    out_v = arr.max(-1)
+    delta = np.ptp(arr, -1)
+    with np.errstate(all='ignore'):
+        out_s = delta / out_v
+    out_s[delta == 0.] = 0.
+    out_s[np.isnan(out_s)] = 0
+    l = out_v * (1 - (out_s / 2))
+    return np.array(l * 255, dtype=np.uint8)
+
+
+def special_gray_convert(imd):
+    """grayconvert.py:38-66, statement for statement (numpy's own min / max / mean / std on the channel views)."""
+    components = ('r', 'g', 'b')
+    d = {}
+    for i, k in enumerate(components):
+        for fun in ['min', 'max', 'mean', 'std']:
+            d[k + '_' + fun] = getattr(np, fun)(imd[:, :, i]) / 255.
+    bright_adjust = round(d['r_mean'] * d['g_mean'] * d['b_mean'] /
+                          (d['b_max'] * (1 - d['r_std']) * (1 - d['g_std']) * (1 - d['b_std'])), 4)
+    low_thres = min(int((196 * d['r_min'] + 14.5) / 1), 50)
+    high_thres = {'r': min(int((35.66 * bright_adjust + 48.5) / 1), 95),
+                  'g': min(int((39.22 * bright_adjust + 44.5) / 1), 95),
+                  'b': min(int((45.16 * bright_adjust + 36.5) / 1), 95)}
+    new_imd = np.copy(imd)
+    for i, c in enumerate(components):
+        new_imd[:, :, i] = level_arr(new_imd[:, :, i], minv=(low_thres * 255) / 100, maxv=(high_thres[c] * 255) / 100)
+    return hsl_lightness_u8(new_imd)

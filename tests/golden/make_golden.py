@@ -20,6 +20,10 @@ Files written next to this script:
                   config 4 cycles through them), config-3 pages (3300x4600 gray thresholds and RGB full)
   modes.npz       small pages in PIL modes other than L / RGB (convert('L') of the original, mrc.py:359-361)
                   and create_threshold_mask vectors
+  grayconvert.npz internetarchivepdf/grayconvert.py: special_gray_convert on small RGB images (inputs included), and the
+                  65536 results of its rgb2hsv + lightness step over every (max, min) pair of a pixel
+  floatimgs.npz   mrc.estimate_noise / mrc.create_threshold_mask on float32 images that do NOT hold whole numbers (the
+                  general form of mrc.py:273-329; the production path only ever passes float32(uint8 image))
   scans.npz       scan-like and adversarial pages, inputs included: JPEG-decoded text in a real (bitmap) font, a photo
                   region, a black scanner border, a white-on-black block, ink in every row, line pitch below the bg radius,
                   constant and two-level pages (+ the last three at config-2 size as digests)
@@ -489,8 +493,87 @@ def scans():
     json.dump(dj, open(os.path.join(HERE, 'digests.json'), 'w'), indent=1, sort_keys=True)
 
 
+def floatimgs():
+    rng = np.random.RandomState(77)
+    d = {}
+    n = 0
+    for i in range(10):
+        h, w = int(rng.randint(9, 150)), int(rng.randint(9, 200))
+        base = synth.synth_page(max(w, 64), max(h, 64), 1, seed=700 + i, noise_sigma=float(rng.choice([0, 3, 9, 20])), line_div=8)[0][:h, :w]
+        kind = i % 5
+        if kind == 0: img = base.astype(np.float32) * np.float32(0.731) + np.float32(11.37)
+        elif kind == 1: img = rng.uniform(0, 255.99, (h, w)).astype(np.float32)
+        elif kind == 2: img = np.clip(base.astype(np.float32) + rng.normal(0, 0.4, (h, w)).astype(np.float32), 0, 255.5).astype(np.float32)
+        elif kind == 3: img = (base.astype(np.float32) / np.float32(3.0))                 # thirds: not representable
+        else: img = np.full((h, w), 100.25, np.float32) + (rng.rand(h, w) < 0.02).astype(np.float32) * np.float32(60.5)
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.min() >= 0 and img.max() < 256
+        dpi = [None, 100, 200][i % 3]
+        sig = mrc.estimate_noise(img)
+        m0 = rng.rand(h, w) < 0.03
+        m = m0.copy()
+        mrc.create_threshold_mask(m, img.copy(), dpi=dpi)
+        d['in_%d' % n] = img
+        d['m0_%d' % n] = np.packbits(m0, axis=1)
+        d['out_%d' % n] = np.packbits(m, axis=1)
+        d['sigma_%d' % n] = np.array(sig, dtype=np.float64)
+        d['dpi_%d' % n] = np.array(-1 if dpi is None else dpi)
+        n += 1
+    d['n'] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, 'floatimgs.npz'), **d)
+
+
+def grayconvert():
+    """grayconvert.py is loaded from where it lies (it needs scikit-image: this interpreter has 0.18.3)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_grayconvert', os.path.join(ref_loader.REF, 'internetarchivepdf', 'grayconvert.py'))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    from skimage.color import rgb2hsv
+    d = {}
+    # the HSV + lightness step over every (max, min): pixel (max, mid, min) in four channel orders must agree
+    mx, mn = np.mgrid[0:256, 0:256]
+    hi, lo = np.maximum(mx, mn), np.minimum(mx, mn)
+    mid = ((hi.astype(int) + lo) // 2).astype(np.uint8)
+    tabs = []
+    for perm in ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 2, 1)):
+        img = np.zeros((256, 256, 3), np.uint8)
+        for ch, v in zip(perm, (hi, mid, lo)):
+            img[:, :, ch] = v
+        hsv = rgb2hsv(img)
+        tabs.append(np.array(hsv[:, :, 2] * (1 - (hsv[:, :, 1] / 2)) * 255, dtype=np.uint8))
+    assert all(np.array_equal(tabs[0], t) for t in tabs)
+    d['hsl_table'] = tabs[0]            # [a][b] for the pixel with max(a, b), min(a, b)
+    rng = np.random.RandomState(20261003)
+    n = 0
+    for i in range(24):
+        kind = i % 6
+        h, w = int(rng.randint(5, 260)), int(rng.randint(5, 340))
+        if i == 0: h, w = 1, 1
+        if i == 1: h, w = 3, 1021
+        if kind == 0: img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        elif kind == 1: img = synth.synth_page(max(w, 64), max(h, 64), 3, seed=900 + i, noise_sigma=float(rng.choice([0, 4, 12])), line_div=12)[0][:h, :w].copy()
+        elif kind == 2: img = np.clip(rng.normal(rng.randint(40, 220), rng.randint(1, 60), (h, w, 3)), 0, 255).astype(np.uint8)
+        elif kind == 3:
+            img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8); img[:, :, rng.randint(3)] = rng.randint(1, 256)
+        elif kind == 4: img = rng.randint(rng.randint(0, 100), rng.randint(150, 256), (h, w, 3)).astype(np.uint8)
+        else: img = np.full((h, w, 3), (int(rng.randint(1, 256)), int(rng.randint(0, 256)), int(rng.randint(1, 256))), np.uint8)   # constant: std 0
+        d['in_%d' % n] = img
+        d['out_%d' % n] = G.special_gray_convert(img.copy())
+        n += 1
+    d['n'] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, 'grayconvert.npz'), **d)
+    # a config-2 sized page as a digest (the GPU box regenerates the input)
+    dj = json.load(open(os.path.join(HERE, 'digests.json')))
+    img, _ = synth.synth_page(4000, 3000, 3, seed=2024, noise_sigma=6.0, line_div=60)
+    t0 = time.time()
+    out = G.special_gray_convert(img.copy())
+    dj['c2_special_gray'] = {'in': sha(img), 'out': sha(out), 'ref_seconds': round(time.time() - t0, 2)}
+    json.dump(dj, open(os.path.join(HERE, 'digests.json'), 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests', 'c5_extra', 'configs', 'modes', 'scans']
+    which = sys.argv[1:] or ['kernels', 'thirdparty', 'pages', 'digests', 'c5_extra', 'configs', 'modes', 'scans', 'grayconvert', 'floatimgs']
     for name in which:
         t0 = time.time()
         globals()[name]()

@@ -234,3 +234,16 @@ def test_round5_bench_lines():
     assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
     assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
     assert g['parity']['pages_checked'] == 128
+
+
+def test_several_ranks_without_rccl_is_a_failing_run_unless_it_is_a_rehearsal():
+    """make_comm falls back to files when RCCL cannot come up; the line says so, and the run now
+    exits 3 instead of 0 -- except for rehearsals that cannot have RCCL (ranks sharing a GPU, the gloo hook)."""
+    import bench
+    assert bench.non_rccl_is_fatal(8, 'files (RCCL bootstrap failed on rank 3)', env={})
+    assert bench.non_rccl_is_fatal(2, 'gloo (test hook)', env={})
+    assert not bench.non_rccl_is_fatal(8, 'files (...)', env={'MRCHIP_BENCH_ALLOW_NON_RCCL': '1'})
+    assert not bench.non_rccl_is_fatal(8, 'rccl (8 ranks, librccl.so.1)', env={})
+    assert not bench.non_rccl_is_fatal(1, 'none (one rank)', env={})
+    src = open(bench.__file__).read()
+    assert 'sys.exit(3)' in src and 'non_rccl_is_fatal(world, transport)' in src

@@ -35,11 +35,19 @@ def test_create_threshold_mask_golden():
         assert np.array_equal(mask, exp), (i, int((mask != exp).sum()))
         assert [k for k, _ in td] == m['keys']
         assert int(mask.sum()) == m['sum']
-    # a float image that does not hold uint8 values is refused, not approximated
+    # round 6: a float32 image that does not hold uint8 values takes the general kernels (tests/test_floatimgs.py);
+    # what is still refused, never approximated: values whose uint8 cast is platform-defined, and other dtypes
+    m = np.zeros((8, 8), bool)
+    mrc.create_threshold_mask(m, np.full((8, 8), 0.5, np.float32))
+    assert np.array_equal(m, O.threshold_image(np.zeros((8, 8), np.uint8), None))
+    assert mrc.estimate_noise(np.full((8, 8), 300.0, np.float32)) == O.estimate_noise(np.full((8, 8), 300.0, np.float32)) or \
+        np.isnan(mrc.estimate_noise(np.full((8, 8), 300.0, np.float32)))
     with pytest.raises(_lib.MrchipError):
-        mrc.create_threshold_mask(np.zeros((8, 8), bool), np.full((8, 8), 0.5, np.float32))
+        mrc.create_threshold_mask(np.zeros((8, 8), bool), np.full((8, 8), 300.0, np.float32))
     with pytest.raises(_lib.MrchipError):
-        mrc.estimate_noise(np.full((8, 8), 300.0, np.float32))
+        mrc.create_threshold_mask(np.zeros((8, 8), bool), np.full((8, 8), -0.5, np.float32))
+    with pytest.raises(_lib.MrchipError):
+        mrc.estimate_noise(np.full((8, 8), 0.5, np.float64))
     with pytest.raises(ValueError):
         mrc.create_threshold_mask(np.zeros((8, 9), bool), np.zeros((8, 8), np.float32))
 
@@ -113,9 +121,16 @@ def test_bregman_is_a_host_passthrough():
         have = True
     except ImportError:
         have = False
-    g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='bregman')
     if not have:
-        with pytest.raises(ImportError):
+        # the missing dependency is reported when the option is GIVEN (the call), with a message
+        # that names it -- not at the first next(), after a page has been uploaded and thresholded
+        with pytest.raises(ImportError, match='scikit-image'):
+            mrc.create_mrc_hocr_components(img, hocr, denoise_mask='bregman')
+        with pytest.raises(ImportError, match='scikit-image'):
+            mrc.denoise_bregman(np.zeros((4, 4), bool))
+        # every other option keeps the reference's lazy behaviour: nothing happens before the first next()
+        g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='no-such-option')
+        with pytest.raises(ValueError):
             next(g)
         return
     from skimage.restoration import denoise_tv_bregman

@@ -215,6 +215,44 @@ def test_gaussian_float32_vertical_sum_stays_inside_its_bound_exhaustively(sig):
     assert bad.value == 0 and 0.0 < worst.value <= (radius + 2) * 2.0 ** -17 + 255 * 2.0 ** -24, (bad.value, worst.value)
 
 
+def test_gaussian_tables_the_float32_form_is_not_proven_for_take_the_float64_form():
+    """the float32 form's undecided band assumes taps >= 0 that add up to 1; mrchip_gaussian_u8 accepts any
+    caller-supplied table of the right radius.  A table with negative outer taps and one that sums to 0.5 must come out as
+    the reference's float64 accumulate gives them (they silently went through the float32 form before)."""
+    lib, ctx = lib_ctx()
+    rng = np.random.RandomState(31)
+    h, w = 131, 977
+    g = rng.randint(60, 201, (h, w)).astype(np.uint8)
+    g[30:90, 200:500] = 128                                      # a flat block: integer results in the middle of it
+    for sig, wts in ((0.6, np.array([-0.05, 0.25, 0.6, 0.25, -0.05])), (0.6, np.array([0.05, 0.1, 0.2, 0.1, 0.05])),
+                     (0.3, np.array([0.3, 0.6, 0.3]))):
+        wts = np.ascontiguousarray(wts, dtype=np.float64)
+        radius = len(wts) // 2
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
+        exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts)
+        assert exp.min() >= 0 and exp.max() < 256
+        assert np.array_equal(out, exp.astype(np.uint8)), (wts.tolist(), int((out != exp.astype(np.uint8)).sum()))
+
+
+def test_gaussian_page_with_saturated_margins_through_the_redo_launch():
+    """a scan with clipped-white margins marks every tile of the margins for the float64 redo; the redo launch now
+    sizes its grid from the tile count (32 count words per workgroup and round).  Result against the oracle on a page large
+    enough for several hundred marked tiles next to noisy ones."""
+    lib, ctx = lib_ctx()
+    rng = np.random.RandomState(32)
+    h, w = 1500, 2100
+    g = np.clip(rng.normal(215, 7, (h, w)), 0, 255).astype(np.uint8)
+    g[:260] = 255; g[-200:] = 255; g[:, :300] = 255; g[:, -280:] = 255        # scanner margins
+    g[700:760, 600:1500] = 0                                                 # a solid bar
+    for sig in (0.62, 1.1):
+        wts, radius = mrc.gaussian_weights(sig)
+        out = np.empty_like(g)
+        _lib.check(lib.mrchip_gaussian_u8(ctx.handle, _lib.ptr(g), _lib.ptr(out), w, h, sig, _lib.ptr(wts, _lib.f64p), radius))
+        exp = O.gaussian_filter(g.astype(np.float32), sig, weights=wts).astype(np.uint8)
+        assert np.array_equal(out, exp), (sig, int((out != exp).sum()))
+
+
 def test_thumbnail_golden_and_random():
     z, cases = thirdparty_cases('thumb')
     lib, ctx = lib_ctx()
