@@ -302,7 +302,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
             hj[i].bits = nullptr; hj[i].bits_pitch = 0; hj[i].no_bytes = 0;
         }
         HIP_TRY(hipMemsetAsync(dcounts, 0, (size_t)nb * 8, s));
-        HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nb * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
+        TRY(upload_1d(s, dj, hj, (size_t)nb * sizeof(SauvolaJob)));
         TRY(launch_sauvola_dev(ctx, s, hj, dj, nb, window, window, 0.1, 128.0, SAUVOLA_INVERT));          // mrc.py:229-235
         TRY(download_1d(s, b->hctrl + L.counts, dcounts, (size_t)nb * 8));
     }
@@ -316,7 +316,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_begin(mrchip_batch *b, int window) {
         hsj[i].as_bool = 0;
         hsj[i].scratch = b->sig_scratch.as<char>() + (size_t)i * b->sig_stride;
     }
-    HIP_TRY(hipMemcpyAsync(dsj, hsj, (size_t)N * sizeof(SigJob), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, dsj, hsj, (size_t)N * sizeof(SigJob)));
     double *dsig = reinterpret_cast<double *>(dctrl + L.sigma);
     TRY(launch_estimate_sigma_jobs(ctx, s, hsj, dsj, N, 0, dsig));
     TRY(download_1d(s, b->hctrl + L.sigma, dsig, (size_t)N * 8));
@@ -392,7 +392,7 @@ static int box_decisions_begin(mrchip_batch *b) {
             hj[k].scratch = b->box_sig_scratch.as<char>() + offs[k];
         }
         double *dsig = reinterpret_cast<double *>(dctrl + L.box_sigma);
-        HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(SigJob), hipMemcpyHostToDevice, s));
+        TRY(upload_1d(s, dj, hj, (size_t)nj * sizeof(SigJob)));
         TRY(launch_estimate_sigma_jobs(ctx, s, hj, dj, nj, 1, dsig));
         TRY(download_1d(s, b->hctrl + L.box_sigma, dsig, (size_t)nj * 8));
         if (!b->box_ev) HIP_TRY(hipEventCreateWithFlags(&b->box_ev, hipEventDisableTiming));
@@ -451,7 +451,7 @@ static int box_decisions_commit(mrchip_batch *b, int or_mode) {
         maxw = std::max(maxw, bi.r - bi.l); maxh = std::max(maxh, bi.b - bi.t);
         if (bi.decision) area += (double)(bi.r - bi.l) * (double)(bi.b - bi.t);
     }
-    HIP_TRY(hipMemcpyAsync(db, hb, (size_t)nb * sizeof(HocrBox), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, db, hb, (size_t)nb * sizeof(HocrBox)));
     return launch_hocr_commit(ctx, s, db, nb, maxw, maxh, area, or_mode);
 }
 
@@ -504,7 +504,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         if (gauss_uses_fused(w, h, max_radius))
             for (int i = 0; i < N; i++) gauss_pad_weights(hg[i], max_radius);
         GaussW *dg = reinterpret_cast<GaussW *>(dctrl + L.gauss);
-        HIP_TRY(hipMemcpyAsync(dg, hg, (size_t)N * sizeof(GaussW), hipMemcpyHostToDevice, s));
+        TRY(upload_1d(s, dg, hg, (size_t)N * sizeof(GaussW)));
         TRY(launch_gaussian_batch(ctx, s, b->gray, b->blur.pl, w, h, dg, b->gtmp.as<float>(), b->gtmp_pitch,
                                   b->gtmp_stride, N, max_radius, fast_ok));                              // mrc.py:311, 325
         thr_src = b->blur.pl;
@@ -529,7 +529,7 @@ MRCHIP_EXPORT int mrchip_batch_mask_finish(mrchip_batch *b, const double *weight
         // rewrites them: they are not stored (1 byte per pixel less to write, 2 less to read-modify-write per box pixel)
         hj[i].no_bytes = fuse_bits ? 1 : 0;
     }
-    HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, dj, hj, (size_t)N * sizeof(SauvolaJob)));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, b->window, b->window, 0.34, 128.0, SAUVOLA_INVERT));   // :325-329 (stored, not OR-ed)
     TRY(box_decisions_commit(b, 1));      // mrc.py:240-266 on top: mask = page threshold | box thresholds
     b->commit_bits = false;
@@ -569,7 +569,7 @@ MRCHIP_EXPORT int mrchip_batch_threshold(mrchip_batch *b, int window, double k) 
         hj[i].dst_inv = nullptr; hj[i].counts = nullptr;
         hj[i].bits = nullptr; hj[i].bits_pitch = 0; hj[i].no_bytes = 0;
     }
-    HIP_TRY(hipMemcpyAsync(dj, hj, (size_t)N * sizeof(SauvolaJob), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, dj, hj, (size_t)N * sizeof(SauvolaJob)));
     TRY(launch_sauvola_dev(ctx, s, hj, dj, N, window, window, k, 128.0, SAUVOLA_INVERT));
     b->state = 4;
     b->bits_valid = 0;

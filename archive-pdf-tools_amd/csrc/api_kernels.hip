@@ -58,7 +58,7 @@ MRCHIP_EXPORT int mrchip_selftest_gauss_fast(mrchip_ctx *ctx, const double *weig
     memset(&G, 0, sizeof(G));
     G.radius = radius;
     for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
-    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, gw.p, &G, sizeof(G)));
     TRY(gauss_fast_selftest(ctx, s, gw.as<GaussW>(), res.as<unsigned long long>(), res.as<unsigned>() + 4));
     unsigned long long h[4] = {0, 0, 0, 0};
     TRY(download_1d(s, h, res.p, 32));
@@ -191,7 +191,7 @@ MRCHIP_EXPORT int mrchip_estimate_sigma(mrchip_ctx *ctx, const uint8_t *arr, int
     DevBuf jb;
     TRY(jb.alloc(ctx, sizeof(SigJob)));
     SigJob job = {m.p, m.pitch, w, h, kind, scratch.as<char>()};
-    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, jb.p, &job, sizeof(job)));
     HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
     TRY(launch_estimate_sigma_jobs(ctx, s, &job, jb.as<SigJob>(), 1, kind, res.as<double>()));
     TRY(download_1d(s, sigma, res.p, sizeof(double)));
@@ -223,7 +223,7 @@ MRCHIP_EXPORT int mrchip_estimate_sigma_f32(mrchip_ctx *ctx, const float *arr, i
     uint8_t *p0 = plane.as<uint8_t>() + PAD;
     TRY(upload_2d(s, p0, pitch, reinterpret_cast<const uint8_t *>(arr), stride * 4, w * 4, h));
     SigJob job = {p0, pitch, w, h, 0, scratch.as<char>()};
-    HIP_TRY(hipMemcpyAsync(jb.p, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, jb.p, &job, sizeof(job)));
     HIP_TRY(hipStreamSynchronize(s));      // `job` lives on this stack frame
     TRY(launch_estimate_sigma_jobs(ctx, s, &job, jb.as<SigJob>(), 1, 2, res.as<double>()));
     TRY(download_1d(s, sigma, res.p, sizeof(double)));
@@ -270,7 +270,7 @@ MRCHIP_EXPORT int mrchip_gaussian_f32(mrchip_ctx *ctx, const float *in, uint8_t 
     memset(&G, 0, sizeof(G));
     G.radius = radius;
     for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
-    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, gw.p, &G, sizeof(G)));
     TRY(upload_2d(s, src.as<uint8_t>(), fp * 4, reinterpret_cast<const uint8_t *>(in), w * 4, w * 4, h));
     HIP_TRY(hipStreamSynchronize(s));      // G lives on this stack frame
     Plane pd;
@@ -312,7 +312,7 @@ MRCHIP_EXPORT int mrchip_gaussian_u8(mrchip_ctx *ctx, const uint8_t *gray, uint8
     for (int i = 0; i < 2 * radius + 1; i++) G.w[i] = weights[i];
     const bool fast_ok = gauss_weights_allow_fast(G);
     if (gauss_uses_fused(w, h, radius)) gauss_pad_weights(G, radius);
-    HIP_TRY(hipMemcpyAsync(gw.p, &G, sizeof(G), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, gw.p, &G, sizeof(G)));
     HIP_TRY(hipStreamSynchronize(s));
     Plane pa, pb;
     pa.p = a.p; pa.pitch = a.pitch; pb.p = b.p; pb.pitch = b.pitch;
@@ -354,7 +354,7 @@ MRCHIP_EXPORT int mrchip_thumbnail_ex(mrchip_ctx *ctx, const uint8_t *in, int w,
     ThumbPlan_scratch2_dims(p, &s2w, &s2h);
     TRY(s2.alloc(ctx, (size_t)s2w * s2h + 256));
     TRY(tab.alloc(ctx, ThumbPlan_table_bytes(p)));
-    HIP_TRY(hipMemcpyAsync(tab.p, p.blob_.data(), p.blob_.size(), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, tab.p, p.blob_.data(), p.blob_.size()));
     TRY(upload_2d(s, src.p, src.pitch, in, w * c, w * c, h));
     Plane psrc, pdst, p1, p2;
     psrc.p = src.p; psrc.pitch = src.pitch;
@@ -409,8 +409,8 @@ MRCHIP_EXPORT int mrchip_special_gray_finish(mrchip_ctx *ctx, const uint8_t *lev
     DevBuf tab;
     TRY(dst.alloc(ctx, g->w, g->h));
     TRY(tab.alloc(ctx, 3 * 256 + 256 * 256));
-    HIP_TRY(hipMemcpyAsync(tab.p, level_luts, 3 * 256, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(tab.as<uint8_t>() + 3 * 256, hsl_table, 256 * 256, hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, tab.p, level_luts, 3 * 256));
+    TRY(upload_1d(s, tab.as<uint8_t>() + 3 * 256, hsl_table, 256 * 256));
     TRY(launch_rgb_level_hsl(ctx, s, g->src.p, g->src.pitch, dst.p, dst.pitch, g->w, g->h, tab.as<uint8_t>()));
     TRY(download_2d(s, out, g->w, dst.p, dst.pitch, g->w, g->h));
     HIP_TRY(hipStreamSynchronize(s));

@@ -124,7 +124,7 @@ MRCHIP_EXPORT int mrchip_comm_bcast(mrchip_comm *c, void *buf, size_t bytes, int
     if (bytes == 0) return 0;
     HIP_TRY(hipSetDevice(c->ctx->device));
     TRY(comm_stage(c, bytes));
-    if (c->rank == root) HIP_TRY(hipMemcpyAsync(c->dbuf, buf, bytes, hipMemcpyHostToDevice, c->s));
+    if (c->rank == root) TRY(upload_1d(c->s, c->dbuf, buf, bytes));
     NCCL_TRY(c, rccl()->bcast(c->dbuf, c->dbuf, bytes, kUint8, root, c->comm, c->s));
     TRY(download_1d(c->s, buf, c->dbuf, bytes));
     HIP_TRY(hipStreamSynchronize(c->s));
@@ -138,7 +138,7 @@ MRCHIP_EXPORT int mrchip_comm_allgather(mrchip_comm *c, const void *send, size_t
     HIP_TRY(hipSetDevice(c->ctx->device));
     TRY(comm_stage(c, bytes * (size_t)(c->world + 1)));
     unsigned char *d = static_cast<unsigned char *>(c->dbuf);
-    HIP_TRY(hipMemcpyAsync(d, send, bytes, hipMemcpyHostToDevice, c->s));
+    TRY(upload_1d(c->s, d, send, bytes));
     NCCL_TRY(c, rccl()->allgather(d, d + bytes, bytes, kUint8, c->comm, c->s));
     TRY(download_1d(c->s, recv, d + bytes, bytes * (size_t)c->world));
     HIP_TRY(hipStreamSynchronize(c->s));
@@ -150,7 +150,7 @@ MRCHIP_EXPORT int mrchip_comm_allreduce_f64(mrchip_comm *c, double *vals, int n,
     if (!c || !vals || n < 1 || (op != 0 && op != 1)) { set_error("comm_allreduce_f64: bad arguments"); return MRCHIP_E_ARG; }
     HIP_TRY(hipSetDevice(c->ctx->device));
     TRY(comm_stage(c, (size_t)n * 8));
-    HIP_TRY(hipMemcpyAsync(c->dbuf, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->s));
+    TRY(upload_1d(c->s, c->dbuf, vals, (size_t)n * 8));
     NCCL_TRY(c, rccl()->allreduce(c->dbuf, c->dbuf, (size_t)n, kFloat64, op == 1 ? kMax : kSum, c->comm, c->s));
     TRY(download_1d(c->s, vals, c->dbuf, (size_t)n * 8));
     HIP_TRY(hipStreamSynchronize(c->s));

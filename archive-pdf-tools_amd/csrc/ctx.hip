@@ -170,9 +170,25 @@ void dev_free(mrchip_ctx *ctx, void *p) {
     ctx->blocks.resize(k);
 }
 
+// Uploads from ordinary (pageable) host memory: the mirror image of the downloads below.  The kernels that read the
+// destination are launched only after the runtime has finished with the copy (the stream is waited for when the source is
+// not page-locked; MRCHIP_UPLOAD_ORDER=0 restores the old behaviour).  Page-locked sources stay asynchronous.
+static bool host_is_pinned(const void *p);
+int order_after_upload(hipStream_t s, const void *host_src) {
+    const char *e = getenv("MRCHIP_UPLOAD_ORDER");
+    if (e && atoi(e) == 0) return 0;
+    if (!host_is_pinned(host_src)) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
     HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, s));
-    return 0;
+    return order_after_upload(s, src);
+}
+
+int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    return order_after_upload(s, src);
 }
 
 // ---- downloads into ordinary (pageable) host memory ------------------------------------------------------------

@@ -141,7 +141,7 @@ int launch_rgb_stats(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int pit
     memset(&init, 0, sizeof(init));
     for (int c = 0; c < 3; c++) init.mn[c] = 255u;
     // (the 80-byte initial value travels inside the memcpy node's own staging: `init` may leave scope at once)
-    HIP_TRY(hipMemcpyAsync(d_stats, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, d_stats, &init, sizeof(init)));
     HIP_TRY(hipStreamSynchronize(s));
     const int rows_per_block = 16;
     const int gx = std::max(1, std::min(cdiv(w >> 2, 256), 8));

@@ -1584,7 +1584,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
         any_skip = any_skip || want_skip[i];
         h_jobs[i].skip_copy = 0; h_jobs[i].rowmap = nullptr;
     }
-    HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
+    TRY(upload_1d(s, d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob)));
     {
         const int st = try_strips(ctx, s, d_jobs, njobs, w, h, c, n_max, mail, (1.0 + 2.0 * c) * w * h * njobs);
         if (st != 0) return st < 0 ? st : 0;
@@ -1644,7 +1644,7 @@ int launch_optimise_jobs(mrchip_ctx *ctx, hipStream_t s, OptJob *h_jobs, OptJob 
             unsigned *maps = reinterpret_cast<unsigned *>(mail->bandq.as<unsigned char>() + 256 + cap * sizeof(OptBand));
             for (int i = 0; i < njobs; i++)
                 if (want_skip[i]) { h_jobs[i].skip_copy = 1; h_jobs[i].rowmap = maps + (size_t)i * nw; }
-            HIP_TRY(hipMemcpyAsync(d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob), hipMemcpyHostToDevice, s));
+            TRY(upload_1d(s, d_jobs, h_jobs, (size_t)njobs * sizeof(OptJob)));
         }
         HIP_TRY(hipMemsetAsync(qctl, 0, 8, s));
         LAUNCH(ctx, s, "optimise_bands", 0.0,

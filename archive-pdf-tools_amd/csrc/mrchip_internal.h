@@ -181,6 +181,7 @@ int launch_rgb_level_hsl(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int
                          int h, const uint8_t *d_tables);
 
 int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
+int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
 int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
 // linear device-to-host copy of pixel data; like download_2d it drains the stream first when `dst` is pageable (ctx.hip)
 int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
