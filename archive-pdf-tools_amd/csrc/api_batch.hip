@@ -652,7 +652,7 @@ static int prepare_thumb(mrchip_batch *b, int Lr, double downsample, int *too_sm
             ThumbPlan_scratch2_dims(p, &s2w, &s2h);
             TRY(b->sc2[Lr].alloc(ctx, N, s2w, s2h, false));
             TRY(b->tables[Lr].alloc(ctx, ThumbPlan_table_bytes(p)));
-            HIP_TRY(hipMemcpy(b->tables[Lr].p, p.blob_.data(), p.blob_.size(), hipMemcpyHostToDevice));
+            TRY(upload_1d(b->s, b->tables[Lr].p, p.blob_.data(), p.blob_.size()));      // (staged: ctx.hip; stream-ordered before the kernels)
         }
     }
     if (p.changed) { b->layer_w[Lr] = p.ow; b->layer_h[Lr] = p.oh; b->layer_small[Lr] = 1; }

@@ -16,6 +16,8 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
+
 // ---- guard bands (debug switch MRCHIP_CANARY=<KiB per side>, default off) -----------------------------------------
 // Kernels of this library read AND write the documented slack of their images (row padding, PAD bytes in front of row 0
 // and behind the last row).  With the switch on, every block the allocator hands out carries `guard` more bytes on both
@@ -39,7 +41,7 @@ static long long canary_verify_block(mrchip_ctx *ctx, DevBlock &b) {
     long long bad = 0;
     for (int side = 0; side < 2; side++) {
         unsigned char *g = (unsigned char *)b.base + (side ? b.bytes - b.guard : 0);
-        if (hipMemcpy(host.data(), g, b.guard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (download_1d(ctx->streams[0], host.data(), g, b.guard) != 0 || hipStreamSynchronize(ctx->streams[0]) != hipSuccess) return -1;
         long long first = -1, n = 0;
         for (size_t i = 0; i < b.guard; i++)
             if (host[i] != CANARY_BYTE) { if (first < 0) first = (long long)i; n++; }
@@ -170,37 +172,19 @@ void dev_free(mrchip_ctx *ctx, void *p) {
     ctx->blocks.resize(k);
 }
 
-// Uploads from ordinary (pageable) host memory: the mirror image of the downloads below.  The kernels that read the
-// destination are launched only after the runtime has finished with the copy (the stream is waited for when the source is
-// not page-locked; MRCHIP_UPLOAD_ORDER=0 restores the old behaviour).  Page-locked sources stay asynchronous.
-static bool host_is_pinned(const void *p);
-int order_after_upload(hipStream_t s, const void *host_src) {
-    const char *e = getenv("MRCHIP_UPLOAD_ORDER");
-    if (e && atoi(e) == 0) return 0;
-    if (!host_is_pinned(host_src)) HIP_TRY(hipStreamSynchronize(s));
-    return 0;
-}
-
-int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
-    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, s));
-    return order_after_upload(s, src);
-}
-
-int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
-    return order_after_upload(s, src);
-}
-
-// ---- downloads into ordinary (pageable) host memory ------------------------------------------------------------
-// Round 6, tests/fuzz_parity.py with 36 processes on one GPU: three host-buffer calls on large inputs (two Sauvola, one
-// thumbnail; profiles/r06_fuzz_runs.txt) returned outputs of which a part -- the bytes the kernel stores LAST: the tail of
-// the thumbnail, one wave's piece of a row -- held the block's old contents: the device-to-host copy enqueued on the
-// stream behind the kernel had read the buffer before the kernel had finished writing it.  The copies in question are
-// `hipMemcpy(2D)Async` into pageable memory, which the runtime does not execute as one ordered DMA command (it stages
-// or pins behind the scenes).  So a download whose destination is not page-locked is no longer handed to the runtime
-// while anything is pending on the stream: the stream is drained first.  Destinations in page-locked memory
-// (mrchip_host_alloc: the streaming pipeline) are true stream-ordered DMAs and stay asynchronous.
-// MRCHIP_DOWNLOAD_ORDER=0 restores the old behaviour (the A/B switch of tests/stress_copy_order.py).
+// ---- copies between the device and ORDINARY (pageable) host memory --------------------------------------------------
+// Round 6 (profiles/r06_README.md, "the copies"): with 16 or more processes on one GPU, host-buffer calls on large
+// images came back wrong hundreds of times per minute -- and in two ways that no kernel can cause: (a) whole 4 KiB pages of
+// the caller's result array still held the pattern the test had put there BEFORE the call (the device-to-host copy never
+// wrote them, although hipStreamSynchronize had returned success), and (b) results that stayed wrong, identically, when the
+// same call was repeated: tables the library uploads once per process had arrived incomplete.  Eight processes: never.
+// What these transfers have in common is `hipMemcpy(2D)Async` on pageable memory, which the runtime serves by pinning the
+// caller's pages on the fly.  The library no longer uses that path: every transfer whose host side is not page-locked goes
+// through a pair of page-locked staging buffers of its own (per thread, 8 MiB each, double-buffered: the DMA of one chunk
+// overlaps the CPU copy of the next), i.e. the only DMA the runtime ever sees is to or from memory pinned with
+// hipHostMalloc.  Page-locked callers' buffers (mrchip_host_alloc: the streaming pipeline) are handed to the runtime as
+// before and stay asynchronous.  A download into pageable memory therefore returns only when the data is in place.
+// MRCHIP_DIRECT_PAGEABLE=1 restores the direct calls (faster for one large page, the A/B switch of tools/runs/diag3.sh).
 static bool host_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof(a));
@@ -211,23 +195,160 @@ static bool host_is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
-int order_before_download(hipStream_t s, const void *host_dst) {
-    const char *e = getenv("MRCHIP_DOWNLOAD_ORDER");          // (read per call: the stress test runs both forms)
-    if (e && atoi(e) == 0) return 0;
-    if (!host_is_pinned(host_dst)) HIP_TRY(hipStreamSynchronize(s));
+static bool direct_pageable() {
+    const char *e = getenv("MRCHIP_DIRECT_PAGEABLE");          // (read per call: the stress scripts run both forms)
+    return e && atoi(e) != 0;
+}
+
+namespace {
+constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+struct Staging {                       // two page-locked slots per thread; `ev[i]` = the last DMA that touched slot i
+    unsigned char *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0;
+    // (nothing is released at thread exit: for the main thread that is process exit, when the HIP runtime may already be
+    // gone; 16 MiB of page-locked memory per thread that ever moved pageable data)
+    int ready() {
+        for (int i = 0; i < 2; i++) {
+            if (!buf[i]) HIP_TRY(hipHostMalloc((void **)&buf[i], STAGE_BYTES, hipHostMallocPortable));
+            if (!ev[i]) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        return 0;
+    }
+    int acquire(int *slot) {           // the slot used least recently, its previous DMA finished
+        TRY(ready());
+        const int i = next;
+        next ^= 1;
+        if (busy[i]) { HIP_TRY(hipEventSynchronize(ev[i])); busy[i] = false; }
+        *slot = i;
+        return 0;
+    }
+};
+thread_local Staging g_stage;
+}  // namespace
+
+// rows of `row_bytes` bytes, `rows` of them; a chunk = as many whole rows as fit a slot (a single row longer than a slot
+// is cut into pieces)
+int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
+    if (rows <= 0 || row_bytes <= 0) return 0;
+    if (host_is_pinned(src) || direct_pageable()) {
+        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    Staging &st = g_stage;
+    if ((size_t)row_bytes > STAGE_BYTES) {
+        for (int y = 0; y < rows; y++)
+            for (size_t o = 0; o < (size_t)row_bytes; o += STAGE_BYTES) {
+                const size_t n = std::min(STAGE_BYTES, (size_t)row_bytes - o);
+                int k;
+                TRY(st.acquire(&k));
+                memcpy(st.buf[k], src + (size_t)y * spitch + o, n);
+                HIP_TRY(hipMemcpyAsync(dst + (size_t)y * dpitch + o, st.buf[k], n, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipEventRecord(st.ev[k], s));
+                st.busy[k] = true;
+            }
+        return 0;
+    }
+    const int per = (int)std::max<size_t>(1, STAGE_BYTES / (size_t)row_bytes);
+    for (int y = 0; y < rows; y += per) {
+        const int n = std::min(per, rows - y);
+        int k;
+        TRY(st.acquire(&k));
+        if (spitch == row_bytes) memcpy(st.buf[k], src + (size_t)y * spitch, (size_t)n * row_bytes);
+        else for (int r = 0; r < n; r++) memcpy(st.buf[k] + (size_t)r * row_bytes, src + (size_t)(y + r) * spitch, (size_t)row_bytes);
+        HIP_TRY(hipMemcpy2DAsync(dst + (size_t)y * dpitch, dpitch, st.buf[k], row_bytes, row_bytes, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(st.ev[k], s));
+        st.busy[k] = true;
+    }
     return 0;
 }
 
-int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
-    TRY(order_before_download(s, dst));
-    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
+int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (host_is_pinned(src) || direct_pageable()) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    Staging &st = g_stage;
+    for (size_t o = 0; o < bytes; o += STAGE_BYTES) {
+        const size_t n = std::min(STAGE_BYTES, bytes - o);
+        int k;
+        TRY(st.acquire(&k));
+        memcpy(st.buf[k], (const unsigned char *)src + o, n);          // (the caller's buffer is free again when this returns)
+        HIP_TRY(hipMemcpyAsync((unsigned char *)dst + o, st.buf[k], n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(st.ev[k], s));
+        st.busy[k] = true;
+    }
     return 0;
+}
+
+// pageable destination: chunk i's DMA (stream-ordered behind the kernels) runs while chunk i-1 is copied out by the CPU;
+// returns with everything in place
+int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows) {
+    if (rows <= 0 || row_bytes <= 0) return 0;
+    if (host_is_pinned(dst) || direct_pageable()) {
+        HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+    Staging &st = g_stage;
+    if ((size_t)row_bytes > STAGE_BYTES) {
+        for (int y = 0; y < rows; y++)
+            TRY(download_1d(s, dst + (size_t)y * dpitch, src + (size_t)y * spitch, (size_t)row_bytes));
+        return 0;
+    }
+    const int per = (int)std::max<size_t>(1, STAGE_BYTES / (size_t)row_bytes);
+    int pend_k = -1, pend_y = 0, pend_n = 0;
+    auto drain = [&]() -> int {
+        if (pend_k < 0) return 0;
+        HIP_TRY(hipEventSynchronize(st.ev[pend_k]));
+        st.busy[pend_k] = false;
+        if (dpitch == row_bytes) memcpy(dst + (size_t)pend_y * dpitch, st.buf[pend_k], (size_t)pend_n * row_bytes);
+        else for (int r = 0; r < pend_n; r++) memcpy(dst + (size_t)(pend_y + r) * dpitch, st.buf[pend_k] + (size_t)r * row_bytes, (size_t)row_bytes);
+        pend_k = -1;
+        return 0;
+    };
+    for (int y = 0; y < rows; y += per) {
+        const int n = std::min(per, rows - y);
+        int k;
+        TRY(st.acquire(&k));               // (never the pending slot: two slots, strictly alternating)
+        HIP_TRY(hipMemcpy2DAsync(st.buf[k], row_bytes, src + (size_t)y * spitch, spitch, row_bytes, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(st.ev[k], s));
+        st.busy[k] = true;
+        TRY(drain());
+        pend_k = k; pend_y = y; pend_n = n;
+    }
+    return drain();
 }
 
 int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
-    TRY(order_before_download(s, dst));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
-    return 0;
+    if (bytes == 0) return 0;
+    if (host_is_pinned(dst) || direct_pageable()) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+    Staging &st = g_stage;
+    int pend_k = -1;
+    size_t pend_o = 0, pend_n = 0;
+    auto drain = [&]() -> int {
+        if (pend_k < 0) return 0;
+        HIP_TRY(hipEventSynchronize(st.ev[pend_k]));
+        st.busy[pend_k] = false;
+        memcpy((unsigned char *)dst + pend_o, st.buf[pend_k], pend_n);
+        pend_k = -1;
+        return 0;
+    };
+    for (size_t o = 0; o < bytes; o += STAGE_BYTES) {
+        const size_t n = std::min(STAGE_BYTES, bytes - o);
+        int k;
+        TRY(st.acquire(&k));
+        HIP_TRY(hipMemcpyAsync(st.buf[k], (const unsigned char *)src + o, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(st.ev[k], s));
+        st.busy[k] = true;
+        TRY(drain());
+        pend_k = k; pend_o = o; pend_n = n;
+    }
+    return drain();
 }
 
 static hipEvent_t get_event(mrchip_ctx *ctx) {

@@ -778,10 +778,12 @@ static const SauvolaCounts *count_tables(mrchip_ctx *ctx, int ww, int wh) {
         cols[nc] = uint4{ms, (unsigned)ss, (unsigned)c, ok ? 1u : 0u};
         if (!ok) e->cols_ok = 0;
     }
+    // (uploads through the library's page-locked staging: ctx.hip, "copies between the device and ordinary host memory")
     if (hipMalloc((void **)&e->d_rows, rows.size() * sizeof(SauvolaRow)) != hipSuccess ||
         hipMalloc((void **)&e->d_cols, cols.size() * sizeof(uint4)) != hipSuccess ||
-        hipMemcpy(e->d_rows, rows.data(), rows.size() * sizeof(SauvolaRow), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(e->d_cols, cols.data(), cols.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) {
+        upload_1d(ctx->streams[0], e->d_rows, rows.data(), rows.size() * sizeof(SauvolaRow)) != 0 ||
+        upload_1d(ctx->streams[0], e->d_cols, cols.data(), cols.size() * sizeof(uint4)) != 0 ||
+        hipStreamSynchronize(ctx->streams[0]) != hipSuccess) {
         delete e;
         return nullptr;
     }
@@ -823,7 +825,7 @@ static const SauvolaTable *decision_table(mrchip_ctx *ctx, double k, double R) {
         hipLaunchKernelGGL(sauvola_t2_build_kernel, dim3(256), dim3(256), 0, st, d_full, k - 1, k * k / R / R);   // pyx:62
         // (the kernel is waited for BEFORE the copy into pageable memory is handed to the runtime: ctx.hip, download_1d)
         good = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
-               hipMemcpy(full.data(), d_full, 65536 * 2, hipMemcpyDeviceToHost) == hipSuccess;
+               download_1d(st, full.data(), d_full, 65536 * 2) == 0 && hipStreamSynchronize(st) == hipSuccess;
     }
     if (d_full) (void)hipFree(d_full);
     if (st) (void)hipStreamDestroy(st);
@@ -850,7 +852,7 @@ static const SauvolaTable *decision_table(mrchip_ctx *ctx, double k, double R) {
         }
     e->bytes = (int)((256 * e->W * 2 + 15) & ~15);
     if (hipMalloc((void **)&e->d_tab, e->bytes) != hipSuccess ||
-        hipMemcpy(e->d_tab, tab.data(), e->bytes, hipMemcpyHostToDevice) != hipSuccess)
+        upload_1d(ctx->streams[0], e->d_tab, tab.data(), e->bytes) != 0 || hipStreamSynchronize(ctx->streams[0]) != hipSuccess)
         return e;
     e->ok = true;
     return e;

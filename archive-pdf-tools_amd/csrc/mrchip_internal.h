@@ -183,9 +183,9 @@ int launch_rgb_level_hsl(mrchip_ctx *ctx, hipStream_t s, const uint8_t *rgb, int
 int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
 int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
 int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int spitch, int row_bytes, int rows);
-// linear device-to-host copy of pixel data; like download_2d it drains the stream first when `dst` is pageable (ctx.hip)
+// Transfers whose host side is pageable go through page-locked staging buffers of the library (ctx.hip); a download into
+// pageable memory returns with the data in place, everything else is stream-ordered and asynchronous
 int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes);
-int order_before_download(hipStream_t s, const void *host_dst);
 
 // profiling hooks: prof_begin returns a token (<0: disabled)
 int prof_begin(mrchip_ctx *ctx, hipStream_t s, const char *name, double alg_bytes);

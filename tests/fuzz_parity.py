@@ -160,7 +160,7 @@ def note(*a):
 def _dump_on_failure(tp, val, tb):
     """a failing case leaves its arrays (inputs, got, expected) and the kernel-form switches in gpurun_out/fuzz_fail_<seed>.npz"""
     try:
-        keep = {k: v for k, v in globals().items() if isinstance(v, np.ndarray) and v.size < 50_000_000 and not k.startswith('_')}
+        keep = {k: v for k, v in globals().items() if isinstance(v, np.ndarray) and v.size < 8_000_000 and not k.startswith('_')}
         keep['env_switches'] = np.array([os.environ.get('MRCHIP_GAUSS_FAST', ''), os.environ.get('MRCHIP_SAUVOLA_COUNTED_STORES', ''),
                                          os.environ.get('MRCHIP_OPT_STRIPS', '')])
         keep['failure'] = np.array([repr(val)])
@@ -275,9 +275,23 @@ while time.time() - t0 < budget:
         g = rnd_img(h, w)
         note('sauvola_big', h, w, ww, wh, k)
         out = np.empty(h * w, np.uint8); exp = np.empty(h * w, np.uint8)
+        if os.environ.get('FUZZ_DIAG'):
+            out[:] = 0xEE                      # (a byte that is still 0xEE afterwards was never written on the host)
         sauvola.binarise_sauvola(g.reshape(-1), out, w, h, ww, wh, k, R)
         O.binarise_sauvola(g.reshape(-1), exp, w, h, ww, wh, k, R)
-        assert np.array_equal(out, exp), ('sauvola_big', h, w, ww, wh, k)
+        if os.environ.get('FUZZ_DIAG') and not np.array_equal(out, exp):
+            # diagnosis mode (round 6): describe the mismatch, run the same call again, go on
+            bad = np.argwhere(out.reshape(h, w) != exp.reshape(h, w))
+            vals, cnts = np.unique(out[out != exp], return_counts=True)
+            again = np.full(h * w, 0xEE, np.uint8)
+            sauvola.binarise_sauvola(g.reshape(-1), again, w, h, ww, wh, k, R)
+            counts['DIAG_mismatch'] = counts.get('DIAG_mismatch', 0) + 1
+            print('DIAG sauvola_big', (h, w, ww, wh, k), 'bad px', len(bad), 'rows', int(bad[:, 0].min()), int(bad[:, 0].max()), 'cols',
+                  int(bad[:, 1].min()), int(bad[:, 1].max()), 'distinct rows', len(np.unique(bad[:, 0])),
+                  'values', dict(zip(vals.tolist()[:6], cnts.tolist()[:6])), 'n_values', len(vals),
+                  'same call again wrong px', int((again != exp).sum()), flush=True)
+        else:
+            assert np.array_equal(out, exp), ('sauvola_big', h, w, ww, wh, k)
         tick('sauvola_big')
     elif what == 9:     # optimise on wide rows (more than 4096 columns: the unpacked kernel)
         h, w = int(rng.randint(1, 60)), int(rng.randint(3000, 9000))

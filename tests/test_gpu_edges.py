@@ -251,3 +251,26 @@ print('canary ok')
     from mrchip import _lib
     if not os.environ.get('MRCHIP_CANARY'):
         assert _lib.default_context().canary_selftest() == 0
+
+
+@pytest.mark.gpu
+def test_sixteen_processes_on_one_gpu_return_exact_results():
+    """Round 6's parity finding (profiles/r06_README.md): with 16 or more processes on one GPU the runtime's transfers to and
+    from PAGEABLE host memory lost 4 KiB pages and delivered incomplete tables -- hundreds of wrong results per minute on
+    large host-buffer calls, none with 8 processes, none once every such transfer goes through the library's own page-locked
+    staging buffers (ctx.hip).  Sixteen processes of tests/fuzz_parity.py (large-window Sauvola calls against the oracle,
+    diagnosis mode: mismatches are counted, the run goes on) for 20 s: not one mismatch.  (The direct path,
+    MRCHIP_DIRECT_PAGEABLE=1, showed ~6 per second in this very setting.)"""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_DIAG='1', FUZZ_FAMILIES='8')
+    env.pop('MRCHIP_DIRECT_PAGEABLE', None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'fuzz_parity.py'), '20', str(8800 + i)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(16)]
+    outs = [p.communicate(timeout=400)[0] for p in procs]
+    cases = 0
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'fuzz ok' in o, o[-1500:]
+        assert 'DIAG' not in o, [l for l in o.split('\n') if l.startswith('DIAG')][:3]
+        cases += int(re.search(r'(\d+) cases', o).group(1))
+    assert cases > 200, cases
