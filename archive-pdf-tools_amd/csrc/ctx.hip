@@ -98,8 +98,9 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
     };
     // A large block is checked against what the device has free BEFORE hipMalloc is asked: an allocation that only
     // just fits leaves the runtime nothing for its own queues and code objects, and what a driver does past that
-    // point is not something a page loop should find out (MRCHIP_HBM_RESERVE_BYTES, default 2 GiB, stays free; the
-    // value is clamped to [0, half the device]: a negative or garbage setting must not refuse every large block).
+    // point is not something a page loop should find out (MRCHIP_HBM_RESERVE_BYTES, default 2 GiB, stays free; a negative
+    // or unparsable setting falls back to the default instead of turning into a huge size_t that refuses every large
+    // block, and the value is capped at the size of the device).
     if (bytes >= ((size_t)64 << 20)) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
@@ -109,7 +110,7 @@ int dev_alloc(mrchip_ctx *ctx, size_t bytes, void **out) {
                 const long long v = strtoll(e, &end, 10);
                 if (end != e && v >= 0) reserve = (size_t)v;
             }
-            reserve = std::min(reserve, tot / 2);
+            reserve = std::min(reserve, tot);
             if (bytes + reserve > fr) {
                 drop_cache();
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes + reserve > fr) {

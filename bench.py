@@ -878,11 +878,14 @@ def link_mix_rate(ctx, mrc, cfg, host_page, rounds=6):
         bt.sync()
     out_bytes = sum(a.nbytes for a in outs[0][0])
     best = 0.0
+    # (an upload invalidates a batch's derived results, so the roles are fixed: the first half of the batches only takes
+    # uploads, the second half only gives its finished layers -- two streams each way, like the pipeline in steady state)
+    ups, dns = bts[:E2E_SLOTS // 2], bts[E2E_SLOTS // 2:]
     for _rep in range(3):
         ctx.sync()
         t = time.perf_counter()
         for r in range(rounds * E2E_SLOTS):
-            up, dn = bts[r % E2E_SLOTS], bts[(r + 2) % E2E_SLOTS]
+            up, dn = ups[r % len(ups)], dns[r % len(dns)]
             dst = outs[r & 1]
             for i in range(E2E_BATCH):
                 up.upload(i, pin_in[i])

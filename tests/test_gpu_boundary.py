@@ -282,3 +282,8 @@ def test_device_memory_report_and_the_reserve_guard():
     assert 'REFUSED' in r.stdout and 'kept in reserve' in r.stdout and 'ALLOCATED' not in r.stdout, r.stdout
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ALLOCATED' in r.stdout, (r.stdout, r.stderr[-800:])
+    # a negative or garbage value must not become a huge unsigned reserve that refuses everything
+    for junk in ('-5', 'lots', ''):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MRCHIP_HBM_RESERVE_BYTES=junk), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0 and 'ALLOCATED' in r.stdout, (junk, r.stdout, r.stderr[-800:])
