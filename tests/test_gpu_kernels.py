@@ -225,7 +225,7 @@ def test_gaussian_tables_the_float32_form_is_not_proven_for_take_the_float64_for
     g = rng.randint(60, 201, (h, w)).astype(np.uint8)
     g[30:90, 200:500] = 128                                      # a flat block: integer results in the middle of it
     for sig, wts in ((0.6, np.array([-0.05, 0.25, 0.6, 0.25, -0.05])), (0.6, np.array([0.05, 0.1, 0.2, 0.1, 0.05])),
-                     (0.3, np.array([0.3, 0.6, 0.3]))):
+                     (0.3, np.array([0.2, 0.5, 0.2]))):
         wts = np.ascontiguousarray(wts, dtype=np.float64)
         radius = len(wts) // 2
         out = np.empty_like(g)
