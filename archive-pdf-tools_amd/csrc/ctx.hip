@@ -185,7 +185,7 @@ void dev_free(mrchip_ctx *ctx, void *p) {
 // overlaps the CPU copy of the next), i.e. the only DMA the runtime ever sees is to or from memory pinned with
 // hipHostMalloc.  Page-locked callers' buffers (mrchip_host_alloc: the streaming pipeline) are handed to the runtime as
 // before and stay asynchronous.  A download into pageable memory therefore returns only when the data is in place.
-// MRCHIP_DIRECT_PAGEABLE=1 restores the direct calls (faster for one large page, the A/B switch of tools/runs/diag3.sh).
+// MRCHIP_DIRECT_PAGEABLE=1 restores the direct calls (faster for one large page, the A/B switch of tools/runs/pageable_ab.sh).
 static bool host_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof(a));

@@ -2,8 +2,8 @@
 # ONE purpose: do the wrong results under many processes go away when no transfer touches pageable memory through the
 # runtime?  Legs: the default (page-locked staging inside the library) and MRCHIP_DIRECT_PAGEABLE=1 (hipMemcpy*Async on the
 # caller's pageable arrays, as before round 6).  <n> processes of tests/fuzz_parity.py, diagnosis mode, large-window Sauvola.
-#   gpurun --timeout 1000 -- 'bash tools/runs/diag3.sh 150 32 r06_diag3'
-SECS=${1:-150}; N=${2:-32}; TAG=${3:-diag3}; FAMS=${4:-8}
+#   gpurun --timeout 1000 -- 'bash tools/runs/pageable_ab.sh 150 32 r06_pageable_ab'
+SECS=${1:-150}; N=${2:-32}; TAG=${3:-pageable_ab}; FAMS=${4:-8}
 mkdir -p gpurun_out
 leg() {
   local name=$1 np=$2; shift 2
