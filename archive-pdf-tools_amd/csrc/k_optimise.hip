@@ -68,7 +68,7 @@ __device__ __forceinline__ RowRegs<C, P> load_row_regs(const uint8_t *mask, int 
 
 // Same with the mask taken from 1-bpp rows: the lane's 4 columns are one nibble of a dword that 8 lanes share; the raw
 // word is returned, the nibble is picked where the row is used
-template <int C, int P, bool NT = false>
+template <int C, int P>
 __device__ __forceinline__ RowRegs<C, P> load_row_regs_bits(const unsigned *mbits, int mwpr, const uint8_t *img, int ipitch,
                                                             int y, int h, unsigned vo_m, unsigned vo_px) {
     static_assert(P == 4, "one nibble per lane");
@@ -78,7 +78,7 @@ __device__ __forceinline__ RowRegs<C, P> load_row_regs_bits(const unsigned *mbit
     gc_u32p pi = (gc_u32p)((img + (size_t)yc * ipitch) + vo_px);
     r.m[0] = pm[0];
 #pragma unroll
-    for (int i = 0; i < P * C / 4; i++) r.px[i] = NT ? __builtin_nontemporal_load(pi + i) : pi[i];
+    for (int i = 0; i < P * C / 4; i++) r.px[i] = pi[i];
     return r;
 }
 
@@ -435,11 +435,7 @@ __device__ __forceinline__ void optimise_packed_rows(const OptJob &J, unsigned c
     const int mwpr = J.mwpr;
     unsigned vo_m = 0, vo_px = 0;          // lane offsets of the row loads, set below (kept opaque inside the row loop)
     auto load_row = [&](int yy, int) {
-#ifdef MRCHIP_EXP_NTLOAD
-        if constexpr (MB) return load_row_regs_bits<C, P, (NCT >= 8)>(mbits, mwpr, img, ipitch, yy, h, vo_m, vo_px);
-#else
         if constexpr (MB) return load_row_regs_bits<C, P>(mbits, mwpr, img, ipitch, yy, h, vo_m, vo_px);
-#endif
         else return load_row_regs_at<C, P>(mask, mpitch, img, ipitch, yy, h, vo_m, vo_px);
     };
 

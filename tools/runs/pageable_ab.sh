@@ -14,7 +14,7 @@ leg() {
   done
   for p in "${pids[@]}"; do wait $p; done
   local mism=$(cat gpurun_out/${TAG}_${name}_*.log | grep -c "^DIAG")
-  local cases=$(grep -h "fuzz ok" gpurun_out/${TAG}_${name}_*.log | sed 's/.* \([0-9][0-9]*\) cases.*/\1/' | paste -sd+ | bc)
+  local cases=$(grep -h "fuzz ok" gpurun_out/${TAG}_${name}_*.log | sed 's/.* \([0-9][0-9]*\) cases.*/\1/' | paste -sd+ | python3 -c "import sys; print(eval(sys.stdin.read() or \"0\"))")
   local clean=$(grep -l "fuzz ok" gpurun_out/${TAG}_${name}_*.log | wc -l)
   local ee=$(cat gpurun_out/${TAG}_${name}_*.log | grep "^DIAG" | grep -c "{238:")
   echo "LEG $name: $np processes x $SECS s: $clean ran to the end, $cases cases, $mism mismatches ($ee with host bytes never written) [$*]"
