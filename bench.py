@@ -286,7 +286,7 @@ def _profile_kernel(kernels, name):
     return max(hits, key=lambda kv: kv[1].get('launches', 0))[1] if hits else None
 
 
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 
 
 def _pick_profile(kind, config, inflight):
