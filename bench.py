@@ -431,6 +431,18 @@ def spawn_ranks(n, argv):
     return 1 if bad else 0
 
 
+_RESULT_FD = None
+
+
+def emit_line(d):
+    """the one JSON line, to the process's real stdout (main() points fd 1 at stderr for everything else)"""
+    data = (json.dumps(d) + '\n').encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -462,6 +474,13 @@ def main():
     if world != a.gpus:
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (a.gpus, world))
         sys.exit(2)
+    # stdout carries exactly ONE line, the result: from here on file descriptor 1 is stderr for everything this process
+    # loads (round 6: on one box of the pool librccl printed its version banner to stdout AFTER the line -- an
+    # ncclCommInitRank that had timed out finished late), and the line is written to the real stdout by emit_line
+    sys.stdout.flush()
+    global _RESULT_FD
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get('MRCHIP_BENCH_DRYRUN'):
         # CPU test hook of the rank plumbing (no GPU, no library): the ranks meet over gloo, rank 0 prints a line
         import torch.distributed as tdist
@@ -472,7 +491,7 @@ def main():
         if os.environ.get('MRCHIP_BENCH_DRYRUN') == 'fail' and rank == world - 1:
             sys.exit(7)
         if rank == 0:
-            print(json.dumps({'dryrun': True, 'n_gpus': world, 'ranks': ids, 'spawned': bool(os.environ.get('MRCHIP_BENCH_SPAWNED'))}))
+            emit_line({'dryrun': True, 'n_gpus': world, 'ranks': ids, 'spawned': bool(os.environ.get('MRCHIP_BENCH_SPAWNED'))})
             sys.stdout.flush()
         comm.barrier()
         tdist.destroy_process_group()       # (a rank that exits with gloo's threads alive aborts now and then: "terminate called ...")
@@ -742,7 +761,7 @@ def main():
             'srchash': sources_hash() if library_is_current() else None,      # of csrc/ + include/: what a profile must match to be quoted
         }
         line.update(extra)
-        print(json.dumps(line))
+        emit_line(line)
     comm.barrier()
     comm.close()
     # A run of several ranks whose control plane is NOT RCCL has measured the sharded pipeline (the line above stands, it
