@@ -247,3 +247,40 @@ def test_several_ranks_without_rccl_is_a_failing_run_unless_it_is_a_rehearsal():
     assert not bench.non_rccl_is_fatal(1, 'none (one rank)', env={})
     src = open(bench.__file__).read()
     assert 'sys.exit(3)' in src and 'non_rccl_is_fatal(world, transport)' in src
+
+
+def test_round6_bench_lines():
+    """The lines of round 6 (profiles/r06_README.md) on the final library sources: contract fields, counter traffic of THIS
+    build attached, the duplex ceiling is a ceiling, the all-cores extrapolation of the CPU baseline, parity of every line."""
+    with open(os.path.join(ROOT, 'profiles', 'r06_bench_c2.json')) as f:
+        txt = f.read().strip()
+    assert len(txt.splitlines()) == 1                      # stdout carries the one line only
+    d = json.loads(txt)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'pipeline_frac', 'head', 'srchash'):
+        assert key in d, key
+    assert d['value'] > 10000 and d['unit'] == 'pages/s' and d['vs_baseline'] is None and d['dtype'] == 'u8' and d['n_gpus'] == 1
+    assert d['head'] and not d['head'].endswith('+') and d['srchash']
+    r = d['roofline']
+    assert r['kernel'] == 'optimise_rgb' and r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / 8000.0) < 1e-4
+    assert r['traffic'] and 1.2 < r['traffic'] / r['alg_bytes_per_launch'] < 1.4 and r['traffic_source']['kernel_sources_equal'] is True
+    assert r['traffic_source']['file'].startswith('profiles/r06_')
+    e = d['e2e']
+    assert e['frac_of_duplex_ceiling'] <= 1.0 and e['link_measured']['stream_mix_copy_only']['pages_per_s'] > 900
+    assert e['duplex_ceiling_pages_per_s_per_gpu'] >= e['duplex_symmetric_pages_per_s_per_gpu']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and not c.get('error') and c['memory_capped'] is True
+    x = c['all_cores_extrapolated']
+    assert x['measured_on_cores'] == c['cores'] and x['host_cpus'] == c['host_cpus'] and x['linear_from_measured'] > c['value']
+    assert d['parity']['mismatches'] == 0 and d['parity']['pages_checked'] == 16
+    assert d['config4_stack']['mismatches'] == 0 and d['config4_stack']['all_pages_present'] and d['rccl_ok'] is True
+    for cfg, unit, least, pages in (('c3', 'pages/s', 5000, 4), ('c3gray', 'GB/s', 1500, 8), ('c5', 'pages/s', 1900, 2)):
+        with open(os.path.join(ROOT, 'profiles', 'r06_bench_%s.json' % cfg)) as f:
+            y = json.loads(f.read().strip().splitlines()[-1])
+        assert y['unit'] == unit and y['value'] > least and y['parity']['mismatches'] == 0 and y['parity']['pages_checked'] == pages
+        assert y['srchash'] == d['srchash']
+    with open(os.path.join(ROOT, 'profiles', 'r06_bench_gpus8_on_one_gpu.json')) as f:
+        g = json.loads(f.read().strip().splitlines()[-1])
+    assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
+    assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
+    assert g['parity']['pages_checked'] == 128
