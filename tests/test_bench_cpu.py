@@ -266,7 +266,7 @@ def test_round6_bench_lines():
     assert r['traffic'] and 1.2 < r['traffic'] / r['alg_bytes_per_launch'] < 1.4 and r['traffic_source']['kernel_sources_equal'] is True
     assert r['traffic_source']['file'].startswith('profiles/r06_')
     e = d['e2e']
-    assert e['frac_of_duplex_ceiling'] <= 1.0 and e['link_measured']['stream_mix_copy_only']['pages_per_s'] > 900
+    assert e['frac_of_duplex_ceiling'] <= 1.0 and e['link_measured']['stream_mix_copy_only']['pages_per_s'] > 500
     assert e['duplex_ceiling_pages_per_s_per_gpu'] >= e['duplex_symmetric_pages_per_s_per_gpu']
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and not c.get('error') and c['memory_capped'] is True
