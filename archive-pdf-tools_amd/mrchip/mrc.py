@@ -21,6 +21,9 @@ RECODE_RUNTIME_WARNING_TOO_SMALL_TO_DOWNSAMPLE = 'too-small-to-downsample'
 DENOISE_NONE = 'none'
 DENOISE_FAST = 'fast'
 DENOISE_BREGMAN = 'bregman'
+# create_mrc_hocr_components: honour edits a caller makes to the yielded mask between next() calls, as the reference's
+# shared array does; False saves a copy and two compares of the mask per page
+SHARED_MASK = True
 
 
 def _window_size(dpi):
@@ -893,12 +896,27 @@ def _mrc_hocr_components(image, hocr_word_data, dpi, downsample, bg_downsample, 
                 timing_data.append(('denoise', time() - t))
         elif denoise_mask not in (DENOISE_NONE, DENOISE_FAST):
             raise ValueError('Invalid denoise option:', denoise_mask)         # mrc.py:396
+        # The reference yields the very array its fg / bg stages read again (mrc.py:399, 413, 439): a caller that edits the
+        # mask between two next() calls gets layers of the edited mask.  The device keeps its own copy, so the yielded
+        # array is compared with what was yielded (one 1-byte-per-pixel copy and compare per stage, SHARED_MASK) and
+        # uploaded again where it changed; a change after the joint fg / bg launch recomputes the layers for bg.
+        mask_seen = mask_arr.copy() if SHARED_MASK else None
+
+        def mask_edited():
+            nonlocal mask_seen
+            if mask_seen is None or np.array_equal(mask_arr, mask_seen):
+                return False
+            page.upload_mask(np.ascontiguousarray(mask_arr, dtype=np.bool_).view(np.uint8))
+            mask_seen = mask_arr.copy()
+            return True
         yield mask_arr
 
         sizes = None
         glay = {}
         for is_bg, ds, key in ((0, fg_downsample, 'fg'), (1, bg_downsample, 'bg')):
             t = time()
+            if mask_edited():
+                sizes = None
             if sizes is None:
                 # both layers are made when the first one is asked for, in one launch: a single page leaves the chip
                 # nearly idle, the two page-layers run side by side (a caller that stops after the mask, recode.py:400-408,

@@ -167,6 +167,39 @@ def test_upload_mask_replaces_the_mask_for_the_layers():
     bt.close()
 
 
+def test_edits_of_the_yielded_mask_reach_the_layers_like_in_the_reference():
+    """SURVEY 8b / VERDICT r5 missing #5: the reference yields the array object its fg and bg stages read again (mrc.py:399,
+    413, 439).  A caller that edits the mask after the first next(), and again after the second, must get the fg of the first
+    edit and the bg of the second -- here against the oracle's generator, which shares its mask array the same way."""
+    rng = np.random.RandomState(12)
+    for (w, h, c) in ((300, 200, 3), (257, 131, 1)):
+        img, hocr = synth.synth_page(w, h, c, seed=21 + c, line_div=10)
+        for kw in (dict(bg_downsample=3), dict(fg_downsample=2, bg_downsample=None)):
+            g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast', **kw)
+            m, em = next(g), next(e)
+            assert np.array_equal(m, em)
+            blot = rng.rand(h, w) < 0.03
+            m |= blot; em |= blot                                   # the caller paints into the mask it was given
+            fg, efg = next(g), next(e)
+            assert np.array_equal(fg, efg), (w, h, c, kw)
+            m[h // 3: h // 2] = False; em[h // 3: h // 2] = False     # ... and edits it again before asking for the background
+            bg, ebg = next(g), next(e)
+            assert bg.shape == ebg.shape and np.array_equal(bg, ebg), (w, h, c, kw)
+    # switched off: the layers are those of the mask as it was yielded
+    old = mrc.SHARED_MASK
+    try:
+        mrc.SHARED_MASK = False
+        img, hocr = synth.synth_page(300, 200, 3, seed=9, line_div=10)
+        g = mrc.create_mrc_hocr_components(img, hocr, denoise_mask='fast')
+        e = O.create_mrc_hocr_components(img, hocr, denoise_mask='fast')
+        m = next(g); next(e)
+        m[:] = True
+        assert np.array_equal(next(g), next(e)) and np.array_equal(next(g), next(e))
+    finally:
+        mrc.SHARED_MASK = old
+
+
 def test_handles_check_shapes_and_order():
     ctx = _lib.default_context()
     bt = mrc.Batch(ctx, 2, 64, 48, 3)
