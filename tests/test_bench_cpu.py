@@ -284,3 +284,11 @@ def test_round6_bench_lines():
     assert g['n_gpus'] == 8 and g['control_plane_ranks'] == 8 and g['rccl_ok'] is False
     assert g['config4_stack']['all_pages_present'] and g['config4_stack']['mismatches'] == 0 and g['parity']['mismatches'] == 0
     assert g['parity']['pages_checked'] == 128
+    # the committed counter profiles are of THESE library sources (csrc/ + include/mrchip.h): a later edit of a kernel or of the
+    # header must come with new profiles, or the driver's line loses `roofline.traffic`
+    import bench
+    for tag in ('r06', 'r06_inflight1', 'r06_c3gray'):
+        with open(os.path.join(ROOT, 'profiles', tag + '_pmc_summary.json')) as f:
+            assert bench.same_kernel_sources(json.load(f)['srchash']), tag
+    t, src = bench.pmc_traffic('optimise_rgb', 21.504e9)
+    assert t and src['kernel_sources_equal'] is True
