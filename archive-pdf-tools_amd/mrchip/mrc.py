@@ -915,12 +915,13 @@ def _mrc_hocr_components(image, hocr_word_data, dpi, downsample, bg_downsample, 
         glay = {}
         for is_bg, ds, key in ((0, fg_downsample, 'fg'), (1, bg_downsample, 'bg')):
             t = time()
-            if mask_edited():
-                sizes = None
             if sizes is None:
                 # both layers are made when the first one is asked for, in one launch: a single page leaves the chip
                 # nearly idle, the two page-layers run side by side (a caller that stops after the mask, recode.py:400-408,
-                # never gets here)
+                # never gets here).  The launch goes out BEFORE the yielded mask is compared with what was yielded: the
+                # compare runs on the host while the kernels run, and only a caller that did edit the mask pays a second launch
+                sizes = page.layers(fg_downsample, bg_downsample)
+            if mask_edited():
                 sizes = page.layers(fg_downsample, bg_downsample)
             (ow, oh), too_small = sizes[is_bg], bool(sizes[2] & (1 << is_bg))
             arr = page.download_layer(is_bg, ow, oh)
