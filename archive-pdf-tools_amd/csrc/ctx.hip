@@ -317,7 +317,14 @@ struct Staging {                       // two page-locked slots per thread; `ev[
         return 0;
     }
 };
-thread_local Staging g_stage;
+// one pair of slots per (thread, device): an event is recorded on streams of the device it was created on
+constexpr int STAGE_MAX_DEVICES = 32;
+thread_local Staging g_stages[STAGE_MAX_DEVICES];
+static Staging &stage_of_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STAGE_MAX_DEVICES) dev = 0;
+    return g_stages[dev];
+}
 }  // namespace
 
 // rows of `row_bytes` bytes, `rows` of them; a chunk = as many whole rows as fit a slot (a single row longer than a slot
@@ -328,7 +335,7 @@ int upload_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int s
         HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, s));
         return 0;
     }
-    Staging &st = g_stage;
+    Staging &st = stage_of_current_device();
     if ((size_t)row_bytes > STAGE_BYTES) {
         for (int y = 0; y < rows; y++)
             for (size_t o = 0; o < (size_t)row_bytes; o += STAGE_BYTES) {
@@ -361,7 +368,7 @@ int upload_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return 0;
     }
-    Staging &st = g_stage;
+    Staging &st = stage_of_current_device();
     for (size_t o = 0; o < bytes; o += STAGE_BYTES) {
         const size_t n = std::min(STAGE_BYTES, bytes - o);
         int k;
@@ -382,7 +389,7 @@ int download_2d(hipStream_t s, uint8_t *dst, int dpitch, const uint8_t *src, int
         HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
         return 0;
     }
-    Staging &st = g_stage;
+    Staging &st = stage_of_current_device();
     if ((size_t)row_bytes > STAGE_BYTES) {
         for (int y = 0; y < rows; y++)
             TRY(download_1d(s, dst + (size_t)y * dpitch, src + (size_t)y * spitch, (size_t)row_bytes));
@@ -417,7 +424,7 @@ int download_1d(hipStream_t s, void *dst, const void *src, size_t bytes) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return 0;
     }
-    Staging &st = g_stage;
+    Staging &st = stage_of_current_device();
     int pend_k = -1;
     size_t pend_o = 0, pend_n = 0;
     auto drain = [&]() -> int {

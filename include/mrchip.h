@@ -10,7 +10,11 @@
  *
  * Buffers passed to the "host-buffer" entry points are ordinary host memory
  * (the numpy arrays the reference passes to its Cython modules); the library
- * stages them through pinned memory.  The "page" entry points keep a page
+ * stages them through page-locked buffers OF ITS OWN and never hands a pageable
+ * pointer to the HIP runtime (round 6: the runtime's transfers on pageable memory
+ * returned wrong data with 16 or more processes per GPU).  Any
+ * pointer may also be page-locked (mrchip_host_alloc): it then goes to the
+ * runtime directly and the copy is a stream-ordered DMA.  The "page" entry points keep a page
  * resident on the device between the three yields of
  * mrc.create_mrc_hocr_components so that pixels cross PCIe once.
  *
@@ -239,9 +243,10 @@ int mrchip_batch_layers(mrchip_batch *b, int which, double fg_downsample, double
                         int *fg_w, int *fg_h, int *bg_w, int *bg_h, int *too_small);
 int mrchip_batch_download_layer(mrchip_batch *b, int page, int is_bg, uint8_t *out);
 /* fg/bg hand-off to the image encoders (mrc.py:523-580 writes each layer to a file for kdu/opj/grok;
- * SURVEY.md 8f rank 2): enqueue-only copy on the batch's stream -- a true asynchronous DMA when `out` is
- * pinned (mrchip_host_alloc) -- so page i can go to its encoder while page i+1 is still on the device.
- * mrchip_batch_sync before the bytes are read. */
+ * SURVEY.md 8f rank 2): enqueue-only copy on the batch's stream when `out` is page-locked (mrchip_host_alloc) -- a
+ * true asynchronous DMA -- so page i can go to its encoder while page i+1 is still on the device; mrchip_batch_sync
+ * before the bytes are read.  With `out` in ordinary memory the call is correct but not asynchronous: it returns when
+ * the bytes are in place (staged through the library's page-locked buffers). */
 int mrchip_batch_download_layer_async(mrchip_batch *b, int page, int is_bg, uint8_t *out);
 /* the same for the mask (bool bytes / 1 bpp): what a streaming caller queues behind mrchip_batch_layers so
  * that batch i-1 leaves over PCIe while batch i is computed and batch i+1 arrives (recode.py:291's page
