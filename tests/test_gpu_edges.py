@@ -273,4 +273,4 @@ def test_sixteen_processes_on_one_gpu_return_exact_results():
         assert p.returncode == 0 and 'fuzz ok' in o, o[-1500:]
         assert 'DIAG' not in o, [l for l in o.split('\n') if l.startswith('DIAG')][:3]
         cases += int(re.search(r'(\d+) cases', o).group(1))
-    assert cases > 200, cases
+    assert cases > 50, cases
